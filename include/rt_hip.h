@@ -1,0 +1,181 @@
+/*
+ * rt_hip.h -- C ABI of librt_hip.so, the MI355X (gfx950) replacement for the
+ * reference's Vulkan compute backend.
+ *
+ * The reference has no FFI of its own.  Its seam is the Rust-level
+ * `vulkan::App` (program/src/modules/vulkan.rs:78-168) and the kernel's
+ * descriptor set 0, bindings 0..8 (shader/src/lib.rs:27-42).  Each entry point
+ * below names the piece of that seam it stands in for.  All structs are the
+ * byte-exact mirrors in rt_abi.h, so a Rust `extern "C"` block can pass
+ * `&CamData`, `&SceneInfo` and the `BufferSceneInfo` vectors straight through.
+ *
+ * Conventions: every function returns 0 (RT_OK) or a negative RT_ERR_* code;
+ * rt_last_error() gives the message (the counterpart of the reference's
+ * anyhow::Result).  One context per GPU.  Calls on one context are not
+ * thread-safe (the reference drives its App from the single winit thread);
+ * different contexts may be driven from different host threads or processes.
+ * Nothing here falls back to the CPU: without a usable HIP device rt_create
+ * fails.
+ */
+#ifndef RT_HIP_H
+#define RT_HIP_H
+
+#include "rt_abi.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_OK 0
+#define RT_ERR_INVALID (-1)  /* bad argument / inconsistent scene buffers    */
+#define RT_ERR_HIP (-2)      /* a HIP runtime call failed                     */
+#define RT_ERR_NO_SCENE (-3) /* render/read before rt_upload_scene            */
+#define RT_ERR_LIMIT (-4)    /* scene exceeds a capacity of this build        */
+
+typedef struct rt_ctx rt_ctx;
+
+/* Sums over every ray segment (trace_ray invocation, trace.rs:195) since the
+ * last rt_reset_stats.  The three traversal sums are only maintained while
+ * RT_OPT_COUNTERS is on. */
+typedef struct rt_stats {
+    uint64_t rays;
+    uint64_t box_tests;       /* hit.rs:80  */
+    uint64_t internal_visits; /* internal nodes that passed their box test */
+    uint64_t triangle_tests;  /* hit.rs:121 */
+    uint64_t paths;           /* pixel samples */
+} rt_stats;
+
+enum {
+    /* 0 = one lane per pixel walks its whole path in one kernel (the shape of
+     *     the reference's shader::main); 1 = wavefront pipeline
+     *     generate / extend / shade / accumulate over a path-state SoA with
+     *     wave64 compaction between bounces. */
+    RT_OPT_PIPELINE = 1,
+    /* 1 = also record, for the FIRST segment of every path, the HitRecord
+     *     (triangle_id, instance_id, t bits) -> rt_read_hits. */
+    RT_OPT_PROBE_HITS = 2,
+    /* 1 = maintain the reference's debug counters (hit.rs:80, 121): first-segment
+     *     per-pixel values -> rt_read_counters, sums -> rt_get_stats. */
+    RT_OPT_COUNTERS = 3,
+    /* 0 = skip the gamma pass (binding 8 is then never written). default 1 */
+    RT_OPT_PRESENT = 4
+};
+
+/* ---- lifecycle: vulkan::App::create / App::destroy (vulkan.rs:124-168, 374) ---- */
+int rt_create(int device, rt_ctx** out);
+void rt_destroy(rt_ctx* ctx);
+/* Message of the last failure on this context (ctx == NULL: last failure of
+ * rt_create on this thread).  Never NULL. */
+const char* rt_last_error(const rt_ctx* ctx);
+/* Run this context's work on the given hipStream_t (NULL = the null stream). */
+int rt_set_stream(rt_ctx* ctx, void* hip_stream);
+int rt_set_option(rt_ctx* ctx, int option, int64_t value);
+
+/* ---- scene: bindings 1-6; replaces create_storage_buffers + the per-frame
+ *      refill in update_buffers (vulkan.rs:238-353).  Copies; the caller keeps
+ *      ownership.  Uploaded once, resident in HBM until the next upload. ---- */
+int rt_upload_scene(rt_ctx* ctx, const rt_scene_info* info,
+                    const rt_vertex* vertices, size_t n_vertices,
+                    const rt_tri* triangles, size_t n_triangles,
+                    const rt_object* objects, size_t n_objects,
+                    const rt_instance* instances, size_t n_instances,
+                    const rt_bvh* bvh, size_t n_bvh);
+/* Per-instance materials (extension, see rt_abi.h).  n must equal the number
+ * of instances.  NULL / 0 restores the reference's constants. */
+int rt_set_materials(rt_ctx* ctx, const rt_material* materials, size_t n);
+void rt_default_material(uint32_t instance_id, rt_material* out);
+
+/* ---- multi-GPU image partition.  This context renders only the strips of
+ *      `strip_height` rows whose strip number is congruent to `rank` modulo
+ *      `world`.  Default (0, 0, 1): the whole canvas. ---- */
+int rt_set_rows(rt_ctx* ctx, uint32_t strip_height, uint32_t rank, uint32_t world);
+
+/* ---- render: App::render minus the swapchain (vulkan.rs:171-236); one
+ *      sample per pixel with the accumulate/reset rule of shader/src/lib.rs:85-98.
+ *      Asynchronous on the context's stream. ---- */
+int rt_render_frame(rt_ctx* ctx, const rt_cam_data* cam);
+/* n consecutive frames; after each one frame += 1 and frames_without_move += 1.0
+ * exactly as the event loop does (main.rs:147-148).  *cam is updated. */
+int rt_render_frames(rt_ctx* ctx, rt_cam_data* cam, uint32_t n);
+int rt_synchronize(rt_ctx* ctx);
+
+/* ---- read-back.  n_pixels must be canvas_width*canvas_height of the last
+ *      rendered frame.  Each call synchronises the stream. ---- */
+int rt_read_acc(rt_ctx* ctx, float* rgba, size_t n_pixels);     /* binding 7 */
+int rt_read_present(rt_ctx* ctx, float* rgba, size_t n_pixels); /* binding 8 */
+int rt_write_acc(rt_ctx* ctx, const float* rgba, size_t n_pixels, uint32_t width, uint32_t height);
+/* parity probes, no counterpart in the reference's API (its HitRecord and
+ * debug counters never leave the shader): first-segment values per pixel */
+int rt_read_hits(rt_ctx* ctx, uint32_t* triangle_id, uint32_t* instance_id, uint32_t* t_bits, size_t n_pixels);
+int rt_read_counters(rt_ctx* ctx, uint32_t* box_tests, uint32_t* triangle_tests, size_t n_pixels);
+int rt_get_stats(rt_ctx* ctx, rt_stats* out);
+int rt_reset_stats(rt_ctx* ctx);
+/* Device address of the accumulation buffer (canvas W*H*4 f32) of the current
+ * canvas size, for callers that reduce it across GPUs themselves. */
+int rt_acc_device_ptr(rt_ctx* ctx, uint32_t width, uint32_t height, void** out);
+/* Kernel-only time of the last rt_render_frame(s) call in milliseconds,
+ * measured with HIP events on the context's stream (synchronises). */
+int rt_last_render_ms(rt_ctx* ctx, float* ms);
+
+/* ======================= host-side scene assembly ===========================
+ * No GPU needed.  Mirrors program/src/modules/mod.rs and bvh.rs. */
+
+typedef struct rt_scene_builder rt_scene_builder;
+
+typedef struct rt_bvh_params {
+    uint32_t root_leaf_max; /* bvh.rs:17      default 5  */
+    uint32_t leaf_max;      /* bvh.rs:75, 85  default 16 */
+    uint32_t max_depth;     /* bvh.rs:5       default 32 */
+    int32_t threads;        /* host threads for the build, default 1 */
+} rt_bvh_params;
+void rt_bvh_params_default(rt_bvh_params* p);
+
+/* parse_obj_file (mod.rs:6-36).  Two-call pattern: pass NULL outputs to get
+ * the counts, then buffers of that size. */
+int rt_parse_obj(const char* text, size_t len, rt_vertex* vertices, size_t* n_vertices,
+                 rt_tri* triangles, size_t* n_triangles);
+/* bvh::create_bvh (bvh.rs:7-28): reorders `triangles` in place, writes up to
+ * *n_nodes nodes (LOCAL indices) and returns the count in *n_nodes.  Pass
+ * nodes == NULL to run the build and get only the count. */
+int rt_create_bvh(const rt_vertex* vertices, size_t n_vertices, rt_tri* triangles, size_t n_triangles,
+                  const rt_bvh_params* params, rt_bvh* nodes, size_t* n_nodes);
+
+/* SceneBuilder (mod.rs:38-134) */
+rt_scene_builder* rt_scene_builder_new(void);
+void rt_scene_builder_free(rt_scene_builder* b);
+int rt_scene_builder_add_obj(rt_scene_builder* b, const char* text, size_t len,
+                             const rt_affine3a* transforms, size_t n_transforms, const rt_bvh_params* params);
+int rt_scene_builder_add_mesh(rt_scene_builder* b, const rt_vertex* vertices, size_t n_vertices,
+                              const rt_tri* triangles, size_t n_triangles,
+                              const rt_affine3a* transforms, size_t n_transforms, const rt_bvh_params* params);
+void rt_scene_builder_sun_orientation(rt_scene_builder* b, float x, float y, float z);
+/* SceneBuilder::build: fills *info and hands out pointers that stay valid
+ * until the builder is freed or extended. */
+int rt_scene_builder_build(rt_scene_builder* b, rt_scene_info* info,
+                           const rt_vertex** vertices, size_t* n_vertices,
+                           const rt_tri** triangles, size_t* n_triangles,
+                           const rt_object** objects, size_t* n_objects,
+                           const rt_instance** instances, size_t* n_instances,
+                           const rt_bvh** bvh, size_t* n_bvh);
+/* rt_upload_scene with the builder's buffers */
+int rt_upload_scene_from_builder(rt_ctx* ctx, rt_scene_builder* b);
+
+/* glam Affine3A::from_scale_rotation_translation (main.rs:23-57); q = x,y,z,w */
+void rt_affine_from_srt(const float scale[3], const float quat_xyzw[4], const float translation[3],
+                        rt_affine3a* out);
+/* glam Quat::from_rotation_x / _y / _z: axis 0/1/2 */
+void rt_quat_from_rotation(int axis, float angle, float quat_xyzw[4]);
+/* Affine3A::inverse in the operation order the trace path uses (trace.rs:87) */
+void rt_affine_inverse(const rt_affine3a* m, rt_affine3a* out);
+
+/* App::update_pos / App::update_mouse (vulkan.rs:95-121) on a CamData.
+ * `orientation` is the App's (yaw, pitch) pair, updated in place. */
+void rt_cam_update_pos(rt_cam_data* cam, const float delta[3]);
+void rt_cam_update_mouse(rt_cam_data* cam, float orientation[2], float mouse_x, float mouse_y);
+
+const char* rt_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_HIP_H */

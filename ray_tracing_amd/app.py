@@ -1,0 +1,155 @@
+"""`App`: the host-side mirror of the reference's `vulkan::App`
+(program/src/modules/vulkan.rs:78-236, 374) on top of librt_hip.so.
+
+Same surface -- create / render / update_pos / update_mouse / destroy and a
+public `cam_data` -- minus the window: frames stay in HBM and are read back on
+request.  Every method goes through the C ABI; there is no CPU path.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+from .scene import Scene, _ptr
+
+
+class App:
+    def __init__(self):
+        raise TypeError("use App.create(cam_data, scene)")
+
+    @classmethod
+    def create(cls, cam_data, scene, device=0, stream=None):
+        """App::create (vulkan.rs:124-168): takes the camera and the scene buffers,
+        uploads the scene once."""
+        self = object.__new__(cls)
+        self._lib = L.load()
+        self._ctx = C.c_void_p()
+        rc = self._lib.rt_create(device, C.byref(self._ctx))
+        if rc != L.RT_OK:
+            msg = self._lib.rt_last_error(None).decode()
+            self._ctx = None
+            raise L.RtError(rc, msg)
+        self.cam_data = cam_data
+        self.orientation = (C.c_float * 2)(0.0, 0.0)  # vulkan.rs:84, 161
+        self.scene = None
+        if stream is not None:
+            self._check(self._lib.rt_set_stream(self._ctx, C.c_void_p(stream)))
+        if scene is not None:
+            self.upload_scene(scene)
+        return self
+
+    # ---- plumbing ---------------------------------------------------------
+    def _check(self, rc):
+        if rc != L.RT_OK:
+            raise L.RtError(rc, self._lib.rt_last_error(self._ctx).decode())
+
+    def destroy(self):
+        """App::destroy (vulkan.rs:374)."""
+        if getattr(self, "_ctx", None):
+            self._lib.rt_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        self.destroy()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.destroy()
+
+    # ---- scene ------------------------------------------------------------
+    def upload_scene(self, scene: Scene):
+        s = scene
+        self._check(self._lib.rt_upload_scene(
+            self._ctx, C.byref(s.info), _ptr(s.vertices), len(s.vertices), _ptr(s.triangles), len(s.triangles),
+            _ptr(s.objects), len(s.objects), _ptr(s.instances), len(s.instances), _ptr(s.bvh), len(s.bvh)))
+        self.scene = scene
+        if scene.materials is not None:
+            self.set_materials(scene.materials)
+
+    def set_materials(self, materials):
+        if materials is None:
+            self._check(self._lib.rt_set_materials(self._ctx, None, 0))
+            return
+        arr = (L.Material * len(materials))(*materials)
+        self._check(self._lib.rt_set_materials(self._ctx, arr, len(materials)))
+
+    def set_option(self, option, value):
+        self._check(self._lib.rt_set_option(self._ctx, option, int(value)))
+
+    def set_rows(self, strip_height, rank, world):
+        self._check(self._lib.rt_set_rows(self._ctx, strip_height, rank, world))
+
+    # ---- camera: vulkan.rs:95-121 ---------------------------------------------
+    def update_pos(self, delta):
+        self._lib.rt_cam_update_pos(C.byref(self.cam_data), (C.c_float * 3)(*delta))
+
+    def update_mouse(self, mouse_x, mouse_y):
+        self._lib.rt_cam_update_mouse(C.byref(self.cam_data), self.orientation, mouse_x, mouse_y)
+
+    # ---- render: vulkan.rs:171-236 + the bookkeeping of main.rs:147-148 ----------
+    def render(self, advance=True):
+        """One sample per pixel with the current cam_data.  With `advance` the
+        frame counters move on exactly as the reference's event loop moves them."""
+        if advance:
+            self._check(self._lib.rt_render_frames(self._ctx, C.byref(self.cam_data), 1))
+        else:
+            self._check(self._lib.rt_render_frame(self._ctx, C.byref(self.cam_data)))
+
+    def render_frames(self, n):
+        self._check(self._lib.rt_render_frames(self._ctx, C.byref(self.cam_data), n))
+
+    def synchronize(self):
+        self._check(self._lib.rt_synchronize(self._ctx))
+
+    # ---- read-back ------------------------------------------------------------
+    def _n(self):
+        return int(self.cam_data.canvas_width) * int(self.cam_data.canvas_height)
+
+    def _shape(self):
+        return int(self.cam_data.canvas_height), int(self.cam_data.canvas_width)
+
+    def read_acc(self):
+        out = np.empty((*self._shape(), 4), np.float32)
+        self._check(self._lib.rt_read_acc(self._ctx, _ptr(out), self._n()))
+        return out
+
+    def read_present(self):
+        out = np.empty((*self._shape(), 4), np.float32)
+        self._check(self._lib.rt_read_present(self._ctx, _ptr(out), self._n()))
+        return out
+
+    def write_acc(self, rgba):
+        rgba = np.ascontiguousarray(rgba, np.float32)
+        h, w = self._shape()
+        self._check(self._lib.rt_write_acc(self._ctx, _ptr(rgba), w * h, w, h))
+
+    def read_hits(self):
+        tri, inst, tb = (np.empty(self._shape(), np.uint32) for _ in range(3))
+        self._check(self._lib.rt_read_hits(self._ctx, _ptr(tri), _ptr(inst), _ptr(tb), self._n()))
+        return tri, inst, tb
+
+    def read_counters(self):
+        box, tt = (np.empty(self._shape(), np.uint32) for _ in range(2))
+        self._check(self._lib.rt_read_counters(self._ctx, _ptr(box), _ptr(tt), self._n()))
+        return box, tt
+
+    def stats(self):
+        s = L.Stats()
+        self._check(self._lib.rt_get_stats(self._ctx, C.byref(s)))
+        return {k: int(getattr(s, k)) for k, _ in L.Stats._fields_}
+
+    def reset_stats(self):
+        self._check(self._lib.rt_reset_stats(self._ctx))
+
+    def acc_device_ptr(self):
+        p = C.c_void_p()
+        h, w = self._shape()
+        self._check(self._lib.rt_acc_device_ptr(self._ctx, w, h, C.byref(p)))
+        return p.value
+
+    def last_render_ms(self):
+        ms = C.c_float()
+        self._check(self._lib.rt_last_render_ms(self._ctx, C.byref(ms)))
+        return float(ms.value)

@@ -1,0 +1,107 @@
+// Device-side data layout, shared by the host code that fills it and the HIP
+// kernels that read it.
+//
+// The reference keeps the scene as 48-byte nodes, 16-byte vertices and 12-byte
+// index triples and reaches a triangle through two dependent loads
+// (shader/src/modules/hit.rs:57-60, 77, 90-91).  Here everything a traversal
+// step needs sits in ONE 64-byte, 64-byte-aligned record:
+//
+//   DevNode  one INTERNAL node = the boxes of both children plus what each
+//            child is, so a visit is four 16-byte loads from one line and the
+//            near/far decision (hit.rs:92-100) needs no further fetch.  Leaves
+//            have no record of their own: their triangle range lives in the
+//            parent's child slot.
+//   DevTri   one triangle = its three vertices (already gathered) plus the
+//            normalised plane normal and plane offset that hit.rs:145-148
+//            recomputes on every test.  The host computes them once with the
+//            same operation order, so the bits are identical.
+#pragma once
+
+#include <cstdint>
+
+namespace rt {
+
+constexpr uint32_t kInternalTag = 0xFFFFFFFFu;
+
+// What a stack slot / child slot refers to.
+//   internal child: a = dense index of its DevNode, b = kInternalTag
+//   leaf child:     a = first triangle, b = last triangle (inclusive, global)
+struct alignas(32) DevChild {
+    float mn[3];
+    uint32_t a;
+    float mx[3];
+    uint32_t b;
+};
+
+struct alignas(64) DevNode {
+    DevChild c[2];
+};
+
+struct alignas(64) DevTri {
+    float p0[3]; float nx;
+    float p1[3]; float ny;
+    float p2[3]; float nz;
+    float d;     float pad[3];
+};
+
+struct alignas(32) DevObject {
+    DevChild root;  // the object's root box and what the root is
+};
+
+struct alignas(16) DevInstance {
+    float inv[12];   // inverse transform: X, Y, Z, T  (object <- world)
+    float fwd[12];   // transform:         X, Y, Z, T  (world <- object)
+    uint32_t object_id;
+    uint32_t mat_kind;
+    uint32_t cull;
+    float specular;
+    float color[3];
+    float specular_roughness;
+    float roughness;
+    float ior;
+    uint32_t pad[2];
+};
+
+struct DevCam {
+    float X[3], Y[3], Z[3], T[3];  // camera-to-world
+    float edge_dist;               // tan(fov/2), evaluated once on the host
+    float fw, fh, aspect;          // W, H, H/W as f32
+    uint32_t W, H;
+    uint32_t depth;
+    uint32_t frame;
+    uint32_t debug_number;
+    uint32_t debug_information;
+    float frames_without_move;
+};
+
+// Which rows of the canvas this context renders: strips of `strip_h` rows are
+// dealt round-robin over `world` contexts and this one takes strip numbers
+// congruent to `rank`.
+struct DevRows {
+    uint32_t strip_h, rank, world, local_rows;
+};
+
+struct DevScene {
+    const DevNode* nodes;
+    const DevTri* tris;
+    const DevObject* objects;
+    const DevInstance* instances;
+    uint32_t n_instances;
+};
+
+struct DevStats {
+    unsigned long long rays, box_tests, internal_visits, triangle_tests, paths;
+};
+
+struct DevFrame {
+    float* acc;      // W*H*4
+    float* present;  // W*H*4
+    uint32_t* hit_triangle;
+    uint32_t* hit_instance;
+    uint32_t* hit_t_bits;
+    uint32_t* box_tests;
+    uint32_t* triangle_tests;
+    DevStats* stats;
+};
+
+}  // namespace rt

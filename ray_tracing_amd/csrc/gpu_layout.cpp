@@ -1,0 +1,171 @@
+#include "gpu_layout.hpp"
+
+#include <cstring>
+
+#include "host_math.hpp"
+#include "host_scene.hpp"
+
+namespace rt {
+
+// trace.rs:15-23 (the three constants) and trace.rs:232-244 (culling by index)
+void default_material(uint32_t instance_id, rt_material& m) {
+    std::memset(&m, 0, sizeof m);
+    if (instance_id == 0) {
+        m.kind = RT_MAT_GENERIC;
+        m.backface_culling = 0;  // material.rs:191-193
+        m.color[0] = m.color[1] = m.color[2] = 1.0f;
+        m.ior = 1.5f;
+    } else if (instance_id == 1) {
+        m.kind = RT_MAT_NORMAL;
+        m.backface_culling = 1;
+    } else {
+        m.kind = RT_MAT_EMISSIVE;  // material_id >= 2, trace.rs:165-167
+        m.backface_culling = 1;
+        m.color[0] = m.color[1] = m.color[2] = 15.0f;
+    }
+}
+
+void apply_material(DevInstance& inst, const rt_material& m) {
+    inst.mat_kind = m.kind;
+    inst.cull = m.backface_culling ? 1u : 0u;
+    inst.color[0] = m.color[0];
+    inst.color[1] = m.color[1];
+    inst.color[2] = m.color[2];
+    inst.specular = m.specular;
+    inst.specular_roughness = m.specular_roughness;
+    inst.roughness = m.roughness;
+    inst.ior = m.ior;
+}
+
+namespace {
+
+void pack_affine(const rt_affine3a& m, float out[12]) {
+    std::memcpy(out + 0, m.x_axis, 12);
+    std::memcpy(out + 3, m.y_axis, 12);
+    std::memcpy(out + 6, m.z_axis, 12);
+    std::memcpy(out + 9, m.translation, 12);
+}
+
+bool make_child(const rt_bvh* bvh, size_t n_bvh, size_t n_triangles, const std::vector<uint32_t>& dense, uint32_t idx,
+                DevChild& out, std::string& err) {
+    if (idx >= n_bvh) {
+        err = "BVH child index " + std::to_string(idx) + " out of range";
+        return false;
+    }
+    const rt_bvh& n = bvh[idx];
+    std::memcpy(out.mn, n.bounding_box.min, 12);
+    std::memcpy(out.mx, n.bounding_box.max, 12);
+    if (n.mode == RT_MODE_CHILDREN) {
+        out.a = dense[idx];
+        out.b = kInternalTag;
+    } else if (n.mode == RT_MODE_TRIANGLES) {
+        uint32_t first = n.child_1_or_first_tri, last = n.child_2_or_last_tri;
+        if (first == last + 1u) {  // `first..=last` with nothing in it
+            out.a = 1;
+            out.b = 0;
+        } else if (first > last || last >= n_triangles) {
+            err = "BVH node " + std::to_string(idx) + ": triangle range [" + std::to_string(first) + ", " +
+                  std::to_string(last) + "] invalid for " + std::to_string(n_triangles) + " triangles";
+            return false;
+        } else {
+            out.a = first;
+            out.b = last;
+        }
+    } else {
+        err = "BVH node " + std::to_string(idx) + ": unknown mode " + std::to_string(n.mode);
+        return false;
+    }
+    return true;
+}
+
+}  // namespace
+
+bool build_gpu_scene(const rt_scene_info& info, const rt_vertex* vertices, size_t n_vertices, const rt_tri* triangles,
+                     size_t n_triangles, const rt_object* objects, size_t n_objects, const rt_instance* instances,
+                     size_t n_instances, const rt_bvh* bvh, size_t n_bvh, GpuScene& out, std::string& err) {
+    if (info.num_instances != n_instances || info.num_bvh_nodes != n_bvh || info.num_triangles != n_triangles) {
+        err = "SceneInfo counts do not match the buffer lengths";
+        return false;
+    }
+    if (n_instances == 0 || n_objects == 0 || n_bvh == 0) {
+        err = "scene has no instances, objects or BVH nodes";
+        return false;
+    }
+    if (n_triangles >= 0x7FFFFFFFull || n_bvh >= 0x7FFFFFFFull || n_vertices > 0xFFFFFFFFull) {
+        err = "scene too large for 32-bit indices";
+        return false;
+    }
+    if ((n_triangles && !triangles) || (n_vertices && !vertices) || !objects || !instances || !bvh) {
+        err = "null scene buffer";
+        return false;
+    }
+
+    // triangles: gather the vertices, precompute the plane (hit.rs:145-148)
+    out.tris.resize(n_triangles);
+    for (size_t i = 0; i < n_triangles; ++i) {
+        const rt_tri& t = triangles[i];
+        if (t.i0 >= n_vertices || t.i1 >= n_vertices || t.i2 >= n_vertices) {
+            err = "triangle " + std::to_string(i) + " references a vertex out of range";
+            return false;
+        }
+        V3 p0 = ld(vertices[t.i0].pos), p1 = ld(vertices[t.i1].pos), p2 = ld(vertices[t.i2].pos);
+        V3 a = p1 - p0, b = p2 - p0;
+        V3 normal = normalize(cross(a, b));
+        float d = -(dot(normal, p0));
+        DevTri& o = out.tris[i];
+        st(o.p0, p0);
+        st(o.p1, p1);
+        st(o.p2, p2);
+        o.nx = normal.x;
+        o.ny = normal.y;
+        o.nz = normal.z;
+        o.d = d;
+        o.pad[0] = o.pad[1] = o.pad[2] = 0.0f;
+    }
+
+    // internal nodes get dense indices in input order
+    std::vector<uint32_t> dense(n_bvh, 0);
+    uint32_t n_internal = 0;
+    for (size_t i = 0; i < n_bvh; ++i)
+        if (bvh[i].mode == RT_MODE_CHILDREN) dense[i] = n_internal++;
+    out.nodes.resize(n_internal);
+    for (size_t i = 0; i < n_bvh; ++i) {
+        if (bvh[i].mode != RT_MODE_CHILDREN) continue;
+        DevNode& dn = out.nodes[dense[i]];
+        if (!make_child(bvh, n_bvh, n_triangles, dense, bvh[i].child_1_or_first_tri, dn.c[0], err)) return false;
+        if (!make_child(bvh, n_bvh, n_triangles, dense, bvh[i].child_2_or_last_tri, dn.c[1], err)) return false;
+    }
+
+    out.objects.resize(n_objects);
+    out.max_depth = 0;
+    for (size_t i = 0; i < n_objects; ++i) {
+        if (!make_child(bvh, n_bvh, n_triangles, dense, objects[i].bvh_root, out.objects[i].root, err)) return false;
+        uint32_t depth = bvh_depth(bvh, n_bvh, objects[i].bvh_root, kMaxBvhDepth);
+        if (depth == 0) {
+            err = "object " + std::to_string(i) + ": BVH is not a tree of at most " + std::to_string(kMaxBvhDepth) +
+                  " levels";
+            return false;
+        }
+        if (depth > out.max_depth) out.max_depth = depth;
+    }
+
+    out.instances.resize(n_instances);
+    for (size_t i = 0; i < n_instances; ++i) {
+        if (instances[i].object_id >= n_objects) {
+            err = "instance " + std::to_string(i) + " references an object out of range";
+            return false;
+        }
+        DevInstance& di = out.instances[i];
+        std::memset(&di, 0, sizeof di);
+        rt_affine3a inv = affine_inverse(instances[i].transform);  // trace.rs:87, hoisted
+        pack_affine(inv, di.inv);
+        pack_affine(instances[i].transform, di.fwd);
+        di.object_id = instances[i].object_id;
+        rt_material m;
+        default_material(uint32_t(i), m);
+        apply_material(di, m);
+    }
+    return true;
+}
+
+}  // namespace rt

@@ -1,0 +1,33 @@
+// Host code that turns the reference-format scene buffers (rt_abi.h) into the
+// device layout of device_types.hpp, validating every index on the way so
+// that no kernel can be launched on a scene that would make it read out of
+// bounds or loop forever.
+#pragma once
+
+#include <string>
+#include <vector>
+
+#include "../../include/rt_abi.h"
+#include "device_types.hpp"
+
+namespace rt {
+
+struct GpuScene {
+    std::vector<DevNode> nodes;  // one per INTERNAL reference node
+    std::vector<DevTri> tris;    // one per triangle, same numbering as the input
+    std::vector<DevObject> objects;
+    std::vector<DevInstance> instances;
+    uint32_t max_depth = 0;  // longest root-to-leaf path in nodes, over all objects
+};
+
+constexpr uint32_t kMaxBvhDepth = 65;  // deepest tree any kernel variant has stack for
+
+// Returns false and fills `err` when the buffers are inconsistent.
+bool build_gpu_scene(const rt_scene_info& info, const rt_vertex* vertices, size_t n_vertices, const rt_tri* triangles,
+                     size_t n_triangles, const rt_object* objects, size_t n_objects, const rt_instance* instances,
+                     size_t n_instances, const rt_bvh* bvh, size_t n_bvh, GpuScene& out, std::string& err);
+
+void apply_material(DevInstance& inst, const rt_material& m);
+void default_material(uint32_t instance_id, rt_material& m);
+
+}  // namespace rt

@@ -1,0 +1,439 @@
+// The GPU half of the C ABI (include/rt_hip.h): context, scene upload, render,
+// read-back.  Stands in for program/src/modules/vulkan.rs of the reference.
+#include <hip/hip_runtime_api.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/rt_hip.h"
+#include "gpu_layout.hpp"
+#include "host_scene.hpp"
+#include "kernels.hpp"
+
+using namespace rt;
+
+struct rt_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    // scene, resident in HBM
+    bool have_scene = false;
+    DevNode* d_nodes = nullptr;
+    DevTri* d_tris = nullptr;
+    DevObject* d_objects = nullptr;
+    DevInstance* d_instances = nullptr;
+    std::vector<DevInstance> h_instances;
+    uint32_t n_instances = 0;
+    uint32_t max_depth = 0;
+
+    // frame buffers, sized for the current canvas
+    uint32_t W = 0, H = 0;
+    float* d_acc = nullptr;
+    float* d_present = nullptr;
+    uint32_t* d_hit_tri = nullptr;
+    uint32_t* d_hit_inst = nullptr;
+    uint32_t* d_hit_t = nullptr;
+    uint32_t* d_box = nullptr;
+    uint32_t* d_tritests = nullptr;
+    DevStats* d_stats = nullptr;
+
+    // options
+    int pipeline = 0;
+    bool probe_hits = false;
+    bool counters = false;
+    bool present = true;
+    uint32_t strip_h = 0, rank = 0, world = 1;
+
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+};
+
+namespace {
+
+thread_local std::string g_create_err;
+
+int fail(rt_ctx* ctx, int code, const std::string& msg) {
+    if (ctx) ctx->err = msg;
+    else g_create_err = msg;
+    return code;
+}
+
+#define RT_HIP(ctx, call)                                                                             \
+    do {                                                                                              \
+        hipError_t e_ = (call);                                                                       \
+        if (e_ != hipSuccess)                                                                         \
+            return fail(ctx, RT_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));          \
+    } while (0)
+
+template <typename T>
+void free_dev(T*& p) {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+}
+
+void free_scene(rt_ctx* c) {
+    free_dev(c->d_nodes);
+    free_dev(c->d_tris);
+    free_dev(c->d_objects);
+    free_dev(c->d_instances);
+    c->have_scene = false;
+}
+
+void free_frame(rt_ctx* c) {
+    free_dev(c->d_acc);
+    free_dev(c->d_present);
+    free_dev(c->d_hit_tri);
+    free_dev(c->d_hit_inst);
+    free_dev(c->d_hit_t);
+    free_dev(c->d_box);
+    free_dev(c->d_tritests);
+    c->W = c->H = 0;
+}
+
+int ensure_frame(rt_ctx* c, uint32_t W, uint32_t H) {
+    if (W == 0 || H == 0 || (uint64_t)W * H > 0x7FFFFFFFull) return fail(c, RT_ERR_INVALID, "bad canvas size");
+    RT_HIP(c, hipSetDevice(c->device));
+    const size_t n = (size_t)W * H;
+    if (c->W != W || c->H != H) {
+        free_frame(c);
+        RT_HIP(c, hipMalloc(&c->d_acc, n * 16));
+        RT_HIP(c, hipMalloc(&c->d_present, n * 16));
+        // binding 7 starts zeroed: the first frame's seeds hash zeros (lib.rs:57-60)
+        RT_HIP(c, hipMemsetAsync(c->d_acc, 0, n * 16, c->stream));
+        RT_HIP(c, hipMemsetAsync(c->d_present, 0, n * 16, c->stream));
+        c->W = W;
+        c->H = H;
+    }
+    if (c->probe_hits && !c->d_hit_tri) {
+        RT_HIP(c, hipMalloc(&c->d_hit_tri, n * 4));
+        RT_HIP(c, hipMalloc(&c->d_hit_inst, n * 4));
+        RT_HIP(c, hipMalloc(&c->d_hit_t, n * 4));
+        RT_HIP(c, hipMemsetAsync(c->d_hit_tri, 0xFF, n * 4, c->stream));
+        RT_HIP(c, hipMemsetAsync(c->d_hit_inst, 0, n * 4, c->stream));
+        RT_HIP(c, hipMemsetAsync(c->d_hit_t, 0, n * 4, c->stream));
+    }
+    if (c->counters && !c->d_box) {
+        RT_HIP(c, hipMalloc(&c->d_box, n * 4));
+        RT_HIP(c, hipMalloc(&c->d_tritests, n * 4));
+        RT_HIP(c, hipMemsetAsync(c->d_box, 0, n * 4, c->stream));
+        RT_HIP(c, hipMemsetAsync(c->d_tritests, 0, n * 4, c->stream));
+    }
+    return RT_OK;
+}
+
+// Rows of the canvas this context owns under the strip partition.
+uint32_t local_rows(uint32_t H, uint32_t strip_h, uint32_t rank, uint32_t world) {
+    if (world <= 1) return H;
+    uint32_t rows = 0;
+    for (uint32_t s = rank; (uint64_t)s * strip_h < H; s += world) {
+        uint32_t y0 = s * strip_h;
+        uint32_t y1 = y0 + strip_h < H ? y0 + strip_h : H;
+        rows += y1 - y0;
+    }
+    return rows;
+}
+
+DevCam make_cam(const rt_cam_data& cam) {
+    DevCam d;
+    std::memcpy(d.X, cam.transform.x_axis, 12);
+    std::memcpy(d.Y, cam.transform.y_axis, 12);
+    std::memcpy(d.Z, cam.transform.z_axis, 12);
+    std::memcpy(d.T, cam.transform.translation, 12);
+    // trace.rs:27-28; tan is evaluated once here instead of once per ray
+    const float pi = 3.14159274101257324f;
+    float fov = (cam.fov * pi / 180.0f) / 2.0f;
+    d.edge_dist = std::tan(fov);
+    d.fw = (float)cam.canvas_width;
+    d.fh = (float)cam.canvas_height;
+    d.aspect = (float)cam.canvas_height / (float)cam.canvas_width;  // trace.rs:31
+    d.W = cam.canvas_width;
+    d.H = cam.canvas_height;
+    d.depth = cam.depth;
+    d.frame = cam.frame;
+    d.debug_number = cam.debug_number;
+    d.debug_information = cam.debug_information;
+    d.frames_without_move = cam.frames_without_move;
+    return d;
+}
+
+int render(rt_ctx* c, const rt_cam_data& cam, uint32_t n_frames) {
+    if (!c->have_scene) return fail(c, RT_ERR_NO_SCENE, "rt_upload_scene has not been called");
+    if (cam.debug_information > RT_DEBUG_BVH_INTERSECTION) return fail(c, RT_ERR_INVALID, "bad debug_information");
+    int rc = ensure_frame(c, cam.canvas_width, cam.canvas_height);
+    if (rc != RT_OK) return rc;
+    if (n_frames == 0) return RT_OK;
+
+    DevScene sc{c->d_nodes, c->d_tris, c->d_objects, c->d_instances, c->n_instances};
+    DevCam dc = make_cam(cam);
+    DevRows rows;
+    rows.strip_h = c->world > 1 ? c->strip_h : cam.canvas_height;
+    rows.rank = c->rank;
+    rows.world = c->world;
+    rows.local_rows = local_rows(cam.canvas_height, rows.strip_h, c->rank, c->world);
+    DevFrame fr;
+    fr.acc = c->d_acc;
+    fr.present = c->present ? c->d_present : nullptr;
+    fr.hit_triangle = c->probe_hits ? c->d_hit_tri : nullptr;
+    fr.hit_instance = c->probe_hits ? c->d_hit_inst : nullptr;
+    fr.hit_t_bits = c->probe_hits ? c->d_hit_t : nullptr;
+    fr.box_tests = c->counters ? c->d_box : nullptr;
+    fr.triangle_tests = c->counters ? c->d_tritests : nullptr;
+    fr.stats = c->d_stats;
+
+    // the debug heat-maps read the counters (trace.rs:97-125)
+    const bool count = c->counters || cam.debug_information != RT_DEBUG_NONE;
+    const uint32_t stack_needed = c->max_depth > 1 ? c->max_depth - 1 : 1;
+
+    RT_HIP(c, hipEventRecord(c->ev0, c->stream));
+    RT_HIP(c, launch_path_kernel(sc, dc, rows, fr, n_frames, stack_needed, count, c->stream));
+    RT_HIP(c, hipEventRecord(c->ev1, c->stream));
+    c->timed = true;
+    return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* rt_version(void) { return "ray_tracing_amd 0.1 (gfx950)"; }
+
+int rt_create(int device, rt_ctx** out) {
+    if (!out) return fail(nullptr, RT_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(nullptr, RT_ERR_HIP, std::string("no HIP device available: ") + hipGetErrorString(e));
+    if (device < 0 || device >= n) return fail(nullptr, RT_ERR_INVALID, "device index out of range");
+    rt_ctx* c = new rt_ctx;
+    c->device = device;
+    auto bail = [&](const char* what, hipError_t err) {
+        std::string msg = std::string(what) + ": " + hipGetErrorString(err);
+        rt_destroy(c);
+        return fail(nullptr, RT_ERR_HIP, msg);
+    };
+    if ((e = hipSetDevice(device)) != hipSuccess) return bail("hipSetDevice", e);
+    if ((e = hipEventCreate(&c->ev0)) != hipSuccess) return bail("hipEventCreate", e);
+    if ((e = hipEventCreate(&c->ev1)) != hipSuccess) return bail("hipEventCreate", e);
+    if ((e = hipMalloc(&c->d_stats, sizeof(DevStats))) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMemset(c->d_stats, 0, sizeof(DevStats))) != hipSuccess) return bail("hipMemset", e);
+    *out = c;
+    return RT_OK;
+}
+
+void rt_destroy(rt_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    free_scene(c);
+    free_frame(c);
+    free_dev(c->d_stats);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    delete c;
+}
+
+const char* rt_last_error(const rt_ctx* c) { return c ? c->err.c_str() : g_create_err.c_str(); }
+
+int rt_set_stream(rt_ctx* c, void* hip_stream) {
+    if (!c) return RT_ERR_INVALID;
+    c->stream = static_cast<hipStream_t>(hip_stream);
+    return RT_OK;
+}
+
+int rt_set_option(rt_ctx* c, int option, int64_t value) {
+    if (!c) return RT_ERR_INVALID;
+    switch (option) {
+        case RT_OPT_PIPELINE:
+            if (value != 0) return fail(c, RT_ERR_INVALID, "unknown pipeline");
+            c->pipeline = (int)value;
+            return RT_OK;
+        case RT_OPT_PROBE_HITS: c->probe_hits = value != 0; return RT_OK;
+        case RT_OPT_COUNTERS: c->counters = value != 0; return RT_OK;
+        case RT_OPT_PRESENT: c->present = value != 0; return RT_OK;
+        default: return fail(c, RT_ERR_INVALID, "unknown option");
+    }
+}
+
+int rt_upload_scene(rt_ctx* c, const rt_scene_info* info, const rt_vertex* vertices, size_t n_vertices,
+                    const rt_tri* triangles, size_t n_triangles, const rt_object* objects, size_t n_objects,
+                    const rt_instance* instances, size_t n_instances, const rt_bvh* bvh, size_t n_bvh) {
+    if (!c || !info) return RT_ERR_INVALID;
+    GpuScene g;
+    std::string err;
+    if (!build_gpu_scene(*info, vertices, n_vertices, triangles, n_triangles, objects, n_objects, instances,
+                         n_instances, bvh, n_bvh, g, err))
+        return fail(c, RT_ERR_INVALID, err);
+    if (g.max_depth > kMaxBvhDepth) return fail(c, RT_ERR_LIMIT, "BVH deeper than this build supports");
+    RT_HIP(c, hipSetDevice(c->device));
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    free_scene(c);
+    // a scene whose only nodes are leaves still needs a valid pointer
+    const size_t n_nodes = g.nodes.empty() ? 1 : g.nodes.size();
+    const size_t n_tris = g.tris.empty() ? 1 : g.tris.size();
+    RT_HIP(c, hipMalloc(&c->d_nodes, n_nodes * sizeof(DevNode)));
+    RT_HIP(c, hipMalloc(&c->d_tris, n_tris * sizeof(DevTri)));
+    RT_HIP(c, hipMalloc(&c->d_objects, g.objects.size() * sizeof(DevObject)));
+    RT_HIP(c, hipMalloc(&c->d_instances, g.instances.size() * sizeof(DevInstance)));
+    if (!g.nodes.empty())
+        RT_HIP(c, hipMemcpy(c->d_nodes, g.nodes.data(), g.nodes.size() * sizeof(DevNode), hipMemcpyHostToDevice));
+    if (!g.tris.empty())
+        RT_HIP(c, hipMemcpy(c->d_tris, g.tris.data(), g.tris.size() * sizeof(DevTri), hipMemcpyHostToDevice));
+    RT_HIP(c, hipMemcpy(c->d_objects, g.objects.data(), g.objects.size() * sizeof(DevObject), hipMemcpyHostToDevice));
+    RT_HIP(c, hipMemcpy(c->d_instances, g.instances.data(), g.instances.size() * sizeof(DevInstance),
+                        hipMemcpyHostToDevice));
+    c->h_instances = g.instances;
+    c->n_instances = (uint32_t)g.instances.size();
+    c->max_depth = g.max_depth;
+    c->have_scene = true;
+    return RT_OK;
+}
+
+void rt_default_material(uint32_t instance_id, rt_material* out) {
+    if (out) default_material(instance_id, *out);
+}
+
+int rt_set_materials(rt_ctx* c, const rt_material* materials, size_t n) {
+    if (!c) return RT_ERR_INVALID;
+    if (!c->have_scene) return fail(c, RT_ERR_NO_SCENE, "rt_upload_scene has not been called");
+    if (materials && n != c->n_instances) return fail(c, RT_ERR_INVALID, "one material per instance is required");
+    for (uint32_t i = 0; i < c->n_instances; ++i) {
+        rt_material m;
+        if (materials) m = materials[i];
+        else default_material(i, m);
+        if (m.kind > RT_MAT_EMISSIVE) return fail(c, RT_ERR_INVALID, "unknown material kind");
+        apply_material(c->h_instances[i], m);
+    }
+    RT_HIP(c, hipSetDevice(c->device));
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    RT_HIP(c, hipMemcpy(c->d_instances, c->h_instances.data(), c->h_instances.size() * sizeof(DevInstance),
+                        hipMemcpyHostToDevice));
+    return RT_OK;
+}
+
+int rt_set_rows(rt_ctx* c, uint32_t strip_height, uint32_t rank, uint32_t world) {
+    if (!c) return RT_ERR_INVALID;
+    if (world <= 1) {
+        c->strip_h = 0;
+        c->rank = 0;
+        c->world = 1;
+        return RT_OK;
+    }
+    if (strip_height == 0 || strip_height % 8 != 0) return fail(c, RT_ERR_INVALID, "strip height must be a multiple of 8");
+    if (rank >= world) return fail(c, RT_ERR_INVALID, "rank >= world");
+    c->strip_h = strip_height;
+    c->rank = rank;
+    c->world = world;
+    return RT_OK;
+}
+
+int rt_render_frame(rt_ctx* c, const rt_cam_data* cam) {
+    if (!c || !cam) return RT_ERR_INVALID;
+    RT_HIP(c, hipSetDevice(c->device));
+    return render(c, *cam, 1);
+}
+
+int rt_render_frames(rt_ctx* c, rt_cam_data* cam, uint32_t n) {
+    if (!c || !cam) return RT_ERR_INVALID;
+    RT_HIP(c, hipSetDevice(c->device));
+    int rc = render(c, *cam, n);
+    if (rc != RT_OK) return rc;
+    for (uint32_t i = 0; i < n; ++i) {  // main.rs:147-148
+        cam->frame += 1;
+        cam->frames_without_move += 1.0f;
+    }
+    return RT_OK;
+}
+
+int rt_synchronize(rt_ctx* c) {
+    if (!c) return RT_ERR_INVALID;
+    RT_HIP(c, hipSetDevice(c->device));
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+static int read_back(rt_ctx* c, void* dst, const void* src, size_t bytes, size_t n_pixels, const char* what) {
+    if (!c || !dst) return RT_ERR_INVALID;
+    if (!src) return fail(c, RT_ERR_INVALID, std::string(what) + " was never produced (option off or nothing rendered)");
+    if (n_pixels != (size_t)c->W * c->H) return fail(c, RT_ERR_INVALID, "n_pixels does not match the canvas");
+    RT_HIP(c, hipSetDevice(c->device));
+    RT_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+int rt_read_acc(rt_ctx* c, float* rgba, size_t n) { return read_back(c, rgba, c ? c->d_acc : nullptr, n * 16, n, "acc"); }
+
+int rt_read_present(rt_ctx* c, float* rgba, size_t n) {
+    return read_back(c, rgba, c ? c->d_present : nullptr, n * 16, n, "present");
+}
+
+int rt_write_acc(rt_ctx* c, const float* rgba, size_t n, uint32_t width, uint32_t height) {
+    if (!c || !rgba) return RT_ERR_INVALID;
+    if (n != (size_t)width * height) return fail(c, RT_ERR_INVALID, "n_pixels does not match width*height");
+    int rc = ensure_frame(c, width, height);
+    if (rc != RT_OK) return rc;
+    RT_HIP(c, hipMemcpyAsync(c->d_acc, rgba, n * 16, hipMemcpyHostToDevice, c->stream));
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+int rt_read_hits(rt_ctx* c, uint32_t* tri, uint32_t* inst, uint32_t* t_bits, size_t n) {
+    int rc = read_back(c, tri, c ? c->d_hit_tri : nullptr, n * 4, n, "hit buffer");
+    if (rc != RT_OK) return rc;
+    rc = read_back(c, inst, c->d_hit_inst, n * 4, n, "hit buffer");
+    if (rc != RT_OK) return rc;
+    return read_back(c, t_bits, c->d_hit_t, n * 4, n, "hit buffer");
+}
+
+int rt_read_counters(rt_ctx* c, uint32_t* box_tests, uint32_t* triangle_tests, size_t n) {
+    int rc = read_back(c, box_tests, c ? c->d_box : nullptr, n * 4, n, "counter buffer");
+    if (rc != RT_OK) return rc;
+    return read_back(c, triangle_tests, c->d_tritests, n * 4, n, "counter buffer");
+}
+
+int rt_get_stats(rt_ctx* c, rt_stats* out) {
+    if (!c || !out) return RT_ERR_INVALID;
+    DevStats s;
+    RT_HIP(c, hipSetDevice(c->device));
+    RT_HIP(c, hipMemcpyAsync(&s, c->d_stats, sizeof s, hipMemcpyDeviceToHost, c->stream));
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    out->rays = s.rays;
+    out->box_tests = s.box_tests;
+    out->internal_visits = s.internal_visits;
+    out->triangle_tests = s.triangle_tests;
+    out->paths = s.paths;
+    return RT_OK;
+}
+
+int rt_reset_stats(rt_ctx* c) {
+    if (!c) return RT_ERR_INVALID;
+    RT_HIP(c, hipSetDevice(c->device));
+    RT_HIP(c, hipMemsetAsync(c->d_stats, 0, sizeof(DevStats), c->stream));
+    return RT_OK;
+}
+
+int rt_acc_device_ptr(rt_ctx* c, uint32_t width, uint32_t height, void** out) {
+    if (!c || !out) return RT_ERR_INVALID;
+    int rc = ensure_frame(c, width, height);
+    if (rc != RT_OK) return rc;
+    *out = c->d_acc;
+    return RT_OK;
+}
+
+int rt_last_render_ms(rt_ctx* c, float* ms) {
+    if (!c || !ms) return RT_ERR_INVALID;
+    if (!c->timed) return fail(c, RT_ERR_INVALID, "nothing has been rendered");
+    RT_HIP(c, hipSetDevice(c->device));
+    RT_HIP(c, hipEventSynchronize(c->ev1));
+    RT_HIP(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return RT_OK;
+}
+
+int rt_upload_scene_from_builder(rt_ctx* c, rt_scene_builder* b);  // defined in rt_host_api.cpp
+
+}  // extern "C"

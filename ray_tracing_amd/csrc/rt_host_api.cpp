@@ -1,0 +1,183 @@
+// The host half of the C ABI (include/rt_hip.h): OBJ parsing, BVH build, scene
+// assembly and the camera helpers.  No GPU calls in this file.
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "../../include/rt_hip.h"
+#include "host_math.hpp"
+#include "host_scene.hpp"
+
+using namespace rt;
+
+struct rt_scene_builder {
+    SceneBuilder sb;
+};
+
+namespace {
+
+BvhBuildParams to_params(const rt_bvh_params* p) {
+    BvhBuildParams out;
+    if (p) {
+        out.root_leaf_max = p->root_leaf_max;
+        out.leaf_max = p->leaf_max < 1 ? 1 : p->leaf_max;
+        out.max_depth = p->max_depth < 1 ? 1 : p->max_depth;
+        out.threads = p->threads;
+    }
+    return out;
+}
+
+}  // namespace
+
+extern "C" {
+
+void rt_bvh_params_default(rt_bvh_params* p) {
+    if (!p) return;
+    BvhBuildParams d;
+    p->root_leaf_max = d.root_leaf_max;
+    p->leaf_max = d.leaf_max;
+    p->max_depth = d.max_depth;
+    p->threads = d.threads;
+}
+
+int rt_parse_obj(const char* text, size_t len, rt_vertex* vertices, size_t* n_vertices, rt_tri* triangles,
+                 size_t* n_triangles) {
+    if (!text || !n_vertices || !n_triangles) return RT_ERR_INVALID;
+    std::vector<rt_vertex> v;
+    std::vector<rt_tri> f;
+    parse_obj(text, len, v, f);
+    if (vertices) {
+        if (*n_vertices < v.size()) return RT_ERR_INVALID;
+        std::memcpy(vertices, v.data(), v.size() * sizeof(rt_vertex));
+    }
+    if (triangles) {
+        if (*n_triangles < f.size()) return RT_ERR_INVALID;
+        std::memcpy(triangles, f.data(), f.size() * sizeof(rt_tri));
+    }
+    *n_vertices = v.size();
+    *n_triangles = f.size();
+    return RT_OK;
+}
+
+int rt_create_bvh(const rt_vertex* vertices, size_t n_vertices, rt_tri* triangles, size_t n_triangles,
+                  const rt_bvh_params* params, rt_bvh* nodes, size_t* n_nodes) {
+    if (!vertices || !triangles || !n_nodes || n_triangles == 0) return RT_ERR_INVALID;
+    for (size_t i = 0; i < n_triangles; ++i)
+        if (triangles[i].i0 >= n_vertices || triangles[i].i1 >= n_vertices || triangles[i].i2 >= n_vertices)
+            return RT_ERR_INVALID;
+    std::vector<rt_bvh> out = create_bvh(vertices, n_vertices, triangles, n_triangles, to_params(params));
+    if (nodes) {
+        if (*n_nodes < out.size()) return RT_ERR_INVALID;
+        std::memcpy(nodes, out.data(), out.size() * sizeof(rt_bvh));
+    }
+    *n_nodes = out.size();
+    return RT_OK;
+}
+
+rt_scene_builder* rt_scene_builder_new(void) { return new rt_scene_builder; }
+
+void rt_scene_builder_free(rt_scene_builder* b) { delete b; }
+
+int rt_scene_builder_add_obj(rt_scene_builder* b, const char* text, size_t len, const rt_affine3a* transforms,
+                             size_t n_transforms, const rt_bvh_params* params) {
+    if (!b || !text || (n_transforms && !transforms)) return RT_ERR_INVALID;
+    std::vector<rt_vertex> v;
+    std::vector<rt_tri> f;
+    parse_obj(text, len, v, f);
+    if (f.empty()) return RT_ERR_INVALID;
+    for (const rt_tri& t : f)
+        if (t.i0 >= v.size() || t.i1 >= v.size() || t.i2 >= v.size()) return RT_ERR_INVALID;
+    b->sb.add_mesh(std::move(v), std::move(f), transforms, n_transforms, to_params(params));
+    return RT_OK;
+}
+
+int rt_scene_builder_add_mesh(rt_scene_builder* b, const rt_vertex* vertices, size_t n_vertices,
+                              const rt_tri* triangles, size_t n_triangles, const rt_affine3a* transforms,
+                              size_t n_transforms, const rt_bvh_params* params) {
+    if (!b || !vertices || !triangles || n_triangles == 0 || (n_transforms && !transforms)) return RT_ERR_INVALID;
+    for (size_t i = 0; i < n_triangles; ++i)
+        if (triangles[i].i0 >= n_vertices || triangles[i].i1 >= n_vertices || triangles[i].i2 >= n_vertices)
+            return RT_ERR_INVALID;
+    std::vector<rt_vertex> v(vertices, vertices + n_vertices);
+    std::vector<rt_tri> f(triangles, triangles + n_triangles);
+    b->sb.add_mesh(std::move(v), std::move(f), transforms, n_transforms, to_params(params));
+    return RT_OK;
+}
+
+void rt_scene_builder_sun_orientation(rt_scene_builder* b, float x, float y, float z) {
+    if (b) b->sb.sun_orientation(x, y, z);
+}
+
+int rt_scene_builder_build(rt_scene_builder* b, rt_scene_info* info, const rt_vertex** vertices, size_t* n_vertices,
+                           const rt_tri** triangles, size_t* n_triangles, const rt_object** objects,
+                           size_t* n_objects, const rt_instance** instances, size_t* n_instances,
+                           const rt_bvh** bvh, size_t* n_bvh) {
+    if (!b || !info) return RT_ERR_INVALID;
+    *info = b->sb.info();
+    if (vertices) *vertices = b->sb.vertices.data();
+    if (n_vertices) *n_vertices = b->sb.vertices.size();
+    if (triangles) *triangles = b->sb.tris.data();
+    if (n_triangles) *n_triangles = b->sb.tris.size();
+    if (objects) *objects = b->sb.objects.data();
+    if (n_objects) *n_objects = b->sb.objects.size();
+    if (instances) *instances = b->sb.instances.data();
+    if (n_instances) *n_instances = b->sb.instances.size();
+    if (bvh) *bvh = b->sb.bvh.data();
+    if (n_bvh) *n_bvh = b->sb.bvh.size();
+    return RT_OK;
+}
+
+int rt_upload_scene_from_builder(rt_ctx* ctx, rt_scene_builder* b) {
+    if (!ctx || !b) return RT_ERR_INVALID;
+    rt_scene_info info = b->sb.info();
+    return rt_upload_scene(ctx, &info, b->sb.vertices.data(), b->sb.vertices.size(), b->sb.tris.data(),
+                           b->sb.tris.size(), b->sb.objects.data(), b->sb.objects.size(), b->sb.instances.data(),
+                           b->sb.instances.size(), b->sb.bvh.data(), b->sb.bvh.size());
+}
+
+void rt_affine_from_srt(const float scale[3], const float q[4], const float translation[3], rt_affine3a* out) {
+    *out = affine_from_srt(ld(scale), q, ld(translation));
+}
+
+// glam Quat::from_rotation_{x,y,z}: (sin, cos) of half the angle
+void rt_quat_from_rotation(int axis, float angle, float q[4]) {
+    float h = angle * 0.5f;
+    float s = std::sin(h), c = std::cos(h);
+    q[0] = q[1] = q[2] = 0.0f;
+    q[3] = c;
+    if (axis >= 0 && axis < 3) q[axis] = s;
+}
+
+void rt_affine_inverse(const rt_affine3a* m, rt_affine3a* out) { *out = affine_inverse(*m); }
+
+// App::update_pos, vulkan.rs:116-121: the scale and rotation survive a
+// decompose / recompose round trip, so only the translation moves.
+void rt_cam_update_pos(rt_cam_data* cam, const float delta[3]) {
+    if (!cam) return;
+    cam->transform.translation[0] += delta[0];
+    cam->transform.translation[1] += delta[1];
+    cam->transform.translation[2] += delta[2];
+}
+
+// App::update_mouse, vulkan.rs:95-114: yaw/pitch integrate the mouse motion,
+// pitch is clamped to +-pi/2, the rotation is rebuilt as Euler YXZ and the
+// old scale and translation are kept.
+void rt_cam_update_mouse(rt_cam_data* cam, float orientation[2], float mouse_x, float mouse_y) {
+    if (!cam || !orientation) return;
+    const float pi = 3.14159274101257324f;
+    orientation[0] += mouse_x * 0.006f;
+    orientation[1] += -mouse_y * 0.006f;
+    if (orientation[1] < -pi / 2.0f) orientation[1] = -pi / 2.0f;
+    if (orientation[1] > pi / 2.0f) orientation[1] = pi / 2.0f;
+    // scale = axis lengths, the first one signed by the determinant
+    V3 X = ld(cam->transform.x_axis), Y = ld(cam->transform.y_axis), Z = ld(cam->transform.z_axis);
+    float det = dot(Z, cross(X, Y));
+    V3 scale = v3(length(X) * (det < 0.0f ? -1.0f : 1.0f), length(Y), length(Z));
+    // q = qy(yaw) * qx(pitch)   (roll is 0)
+    float hy = orientation[0] * 0.5f, hx = orientation[1] * 0.5f;
+    float sy = std::sin(hy), cy = std::cos(hy), sx = std::sin(hx), cx = std::cos(hx);
+    float q[4] = {cy * sx, sy * cx, -sy * sx, cy * cx};
+    cam->transform = affine_from_srt(scale, q, ld(cam->transform.translation));
+}
+
+}  // extern "C"

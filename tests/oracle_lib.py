@@ -1,0 +1,151 @@
+"""ctypes binding of the CPU oracle (oracle/rt_oracle.h).  Test infrastructure:
+only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from ray_tracing_amd import _lib as L
+from ray_tracing_amd.scene import Scene, _ptr
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_SO = os.path.join(ORACLE_DIR, "_build", "librt_oracle.so")
+
+TRIG_LIBM, TRIG_DET = 0, 1
+
+
+class OrcScene(C.Structure):
+    _fields_ = [("info", L.SceneInfo),
+                ("vertices", C.c_void_p), ("n_vertices", C.c_size_t),
+                ("triangles", C.c_void_p), ("n_triangles", C.c_size_t),
+                ("objects", C.c_void_p), ("n_objects", C.c_size_t),
+                ("instances", C.c_void_p), ("n_instances", C.c_size_t),
+                ("bvh", C.c_void_p), ("n_bvh", C.c_size_t),
+                ("materials", C.c_void_p), ("n_materials", C.c_size_t)]
+
+
+class OrcStats(C.Structure):
+    _fields_ = [("rays", C.c_uint64), ("box_tests", C.c_uint64), ("internal_visits", C.c_uint64),
+                ("triangle_tests", C.c_uint64), ("paths", C.c_uint64)]
+
+
+class OrcProbe(C.Structure):
+    _fields_ = [("hit_triangle", C.c_void_p), ("hit_instance", C.c_void_p), ("hit_t_bits", C.c_void_p),
+                ("box_tests", C.c_void_p), ("triangle_tests", C.c_void_p)]
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(ORACLE_SO) and os.path.exists(os.path.join(ORACLE_DIR, "Makefile")):
+        subprocess.check_call(["make", "-C", ORACLE_DIR], stdout=subprocess.DEVNULL)
+    lib = C.CDLL(ORACLE_SO)
+    f, u32, vp = C.c_float, C.c_uint32, C.c_void_p
+    F3 = C.POINTER(C.c_float)
+    lib.orc_get_seed.restype = u32
+    lib.orc_get_seed.argtypes = [u32, u32, u32, f, f, f]
+    lib.orc_xor_shift.restype = u32
+    lib.orc_xor_shift.argtypes = [u32]
+    lib.orc_rand_float.restype = f
+    lib.orc_rand_float.argtypes = [C.POINTER(u32), f, f]
+    for name in ("orc_acos_approx", "orc_det_sin", "orc_det_cos"):
+        getattr(lib, name).restype = f
+        getattr(lib, name).argtypes = [f]
+    lib.orc_hits_bounding.restype = f
+    lib.orc_hits_bounding.argtypes = [F3, F3, F3, F3]
+    lib.orc_triangle_ray_intersect.restype = f
+    lib.orc_triangle_ray_intersect.argtypes = [F3, F3, F3, F3, F3, f, f, C.c_int]
+    lib.orc_affine_inverse.restype = None
+    lib.orc_affine_inverse.argtypes = [C.POINTER(L.Affine3A), C.POINTER(L.Affine3A)]
+    lib.orc_transform_point3.restype = None
+    lib.orc_transform_point3.argtypes = [C.POINTER(L.Affine3A), F3, F3]
+    lib.orc_transform_vector3.restype = None
+    lib.orc_transform_vector3.argtypes = [C.POINTER(L.Affine3A), F3, F3]
+    lib.orc_camera_ray.restype = None
+    lib.orc_camera_ray.argtypes = [C.POINTER(L.CamData), f, f, F3, F3]
+    lib.orc_sky.restype = None
+    lib.orc_sky.argtypes = [F3, F3]
+    lib.orc_default_material.restype = None
+    lib.orc_default_material.argtypes = [u32, C.POINTER(L.Material)]
+    lib.orc_mesh_hit.restype = None
+    lib.orc_mesh_hit.argtypes = [C.POINTER(OrcScene), u32, F3, F3, f, f, u32, C.c_int, C.POINTER(u32)]
+    lib.orc_get_color.restype = None
+    lib.orc_get_color.argtypes = [C.POINTER(OrcScene), C.POINTER(L.CamData), u32, u32, u32, C.c_int, F3]
+    lib.orc_render_frame.restype = C.c_int
+    lib.orc_render_frame.argtypes = [C.POINTER(OrcScene), C.POINTER(L.CamData), vp, vp, C.POINTER(OrcProbe),
+                                     C.POINTER(OrcStats), u32, u32, C.c_int, C.c_int]
+    _lib = lib
+    return lib
+
+
+def f3(*v):
+    return (C.c_float * 3)(*v)
+
+
+def f32_bits(x):
+    return int(np.float32(x).view(np.uint32))
+
+
+def bits_f32(u):
+    return float(np.uint32(u).view(np.float32))
+
+
+def orc_scene(scene: Scene, materials=None):
+    """OrcScene view of a Scene.  Keeps references to the arrays alive."""
+    s = OrcScene()
+    s.info = scene.info
+    s.vertices, s.n_vertices = _ptr(scene.vertices), len(scene.vertices)
+    s.triangles, s.n_triangles = _ptr(scene.triangles), len(scene.triangles)
+    s.objects, s.n_objects = _ptr(scene.objects), len(scene.objects)
+    s.instances, s.n_instances = _ptr(scene.instances), len(scene.instances)
+    s.bvh, s.n_bvh = _ptr(scene.bvh), len(scene.bvh)
+    keep = [scene]
+    mats = materials if materials is not None else scene.materials
+    if mats is not None:
+        arr = (L.Material * len(mats))(*mats)
+        s.materials, s.n_materials = C.cast(arr, C.c_void_p), len(mats)
+        keep.append(arr)
+    s._keep = keep
+    return s
+
+
+class OracleRenderer:
+    """Frame-by-frame CPU rendering with the accumulate rule of shader/src/lib.rs."""
+
+    def __init__(self, scene: Scene, cam: L.CamData, trig=TRIG_DET, threads=8, materials=None):
+        self.lib = load()
+        self.scene = orc_scene(scene, materials)
+        self.cam = L.CamData.from_buffer_copy(cam)
+        self.trig, self.threads = trig, threads
+        h, w = int(cam.canvas_height), int(cam.canvas_width)
+        self.acc = np.zeros((h, w, 4), np.float32)
+        self.present = np.zeros((h, w, 4), np.float32)
+        self.hit_triangle = np.zeros((h, w), np.uint32)
+        self.hit_instance = np.zeros((h, w), np.uint32)
+        self.hit_t_bits = np.zeros((h, w), np.uint32)
+        self.box_tests = np.zeros((h, w), np.uint32)
+        self.triangle_tests = np.zeros((h, w), np.uint32)
+        self.stats = OrcStats()
+
+    def render(self, n_frames=1, rows=None):
+        h = int(self.cam.canvas_height)
+        y0, y1 = rows if rows else (0, h)
+        probe = OrcProbe(_ptr(self.hit_triangle), _ptr(self.hit_instance), _ptr(self.hit_t_bits),
+                         _ptr(self.box_tests), _ptr(self.triangle_tests))
+        for _ in range(n_frames):
+            rc = self.lib.orc_render_frame(C.byref(self.scene), C.byref(self.cam), _ptr(self.acc), _ptr(self.present),
+                                           C.byref(probe), C.byref(self.stats), y0, y1, self.threads, self.trig)
+            assert rc == 0
+            # the event loop's bookkeeping, main.rs:147-148
+            self.cam.frame += 1
+            self.cam.frames_without_move = float(np.float32(self.cam.frames_without_move) + np.float32(1.0))
+        return self
+
+    def stats_dict(self):
+        return {k: int(getattr(self.stats, k)) for k, _ in OrcStats._fields_}
