@@ -41,7 +41,7 @@ RT_DEV float dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 RT_DEV V3 cross(V3 a, V3 b) {
     return V3{a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y};
 }
-RT_DEV float length(V3 a) { return __fsqrt_rn(dot(a, a)); }
+RT_DEV float length(V3 a) { return __builtin_sqrtf(dot(a, a)); }
 RT_DEV V3 normalize(V3 a) {
     float r = 1.0f / length(a);
     return a * r;
@@ -84,7 +84,7 @@ RT_DEV float rand_float(uint32_t& seed, float lo, float hi) {
 RT_DEV float acos_approx(float v) {
     float x = fabsf(v);
     float res = -0.155972f * x + 1.56467f;
-    res *= __fsqrt_rn(1.0f - x);
+    res *= __builtin_sqrtf(1.0f - x);
     return v >= 0.0f ? res : kPi - res;
 }
 
@@ -313,7 +313,7 @@ RT_DEV V3 generic_reflect(V3 in_dir, V3 normal, float roughness, uint32_t& seed)
 RT_DEV V3 glam_refract(V3 i, V3 n, float eta) {
     float n_dot_i = dot(n, i);
     float k = 1.0f - eta * eta * (1.0f - n_dot_i * n_dot_i);
-    if (k >= 0.0f) return i * eta - n * (eta * n_dot_i + __fsqrt_rn(k));
+    if (k >= 0.0f) return i * eta - n * (eta * n_dot_i + __builtin_sqrtf(k));
     return v3(0.0f, 0.0f, 0.0f);
 }
 
@@ -327,7 +327,7 @@ RT_DEV float powi5(float x) {
 RT_DEV int generic_bxdf(const DevInstance& m, V3& color, Ray& ray, V3 normal, float t, uint32_t& seed) {
     Ray in_ray = ray;
     float cos_theta = dot(in_ray.dir, normal);
-    float sin_theta = __fsqrt_rn(1.0f - cos_theta * cos_theta);
+    float sin_theta = __builtin_sqrtf(1.0f - cos_theta * cos_theta);
     V3 hit_pos = in_ray.pos + in_ray.dir * t;
 
     if (m.specular > 0.0f) {
@@ -389,7 +389,7 @@ RT_DEV int emissive_bxdf(const DevInstance& m, V3& color, Ray& ray, V3 normal, f
     Ray in_ray = ray;
     V3 ray_reversed = -normalize(in_ray.dir);
     float dot_product = fabsf(dot(ray_reversed, normal));
-    V3 stop = ld3(m.color) * __fsqrt_rn(dot_product);
+    V3 stop = ld3(m.color) * __builtin_sqrtf(dot_product);
     ray.pos = in_ray.pos + in_ray.dir * t;
     ray.dir = v3(0.0f, 0.0f, 0.0f);
     color = color * stop;
