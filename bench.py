@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""Throughput of the trace path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[2], the one the Mrays/s metric and its 1/2/4/8
+GPU figures are quoted on): a seeded ~1.0 M-triangle procedural scene at
+1920x1080, 16 accumulated one-sample frames per step, depth 10, scene resident
+in HBM before the timed region.  With N > 1 (launched by torch.distributed.run,
+one process per GPU) the canvas is dealt to the ranks in interleaved 8-row
+strips; there is no collective in the data path, so the job is the same fixed
+image whatever N is ("strong" scaling).  A ray is one trace_ray invocation
+(shader/src/modules/trace.rs:195), primary and secondary alike; the count comes
+from the device's own counter.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
+WIDTH, HEIGHT, FRAMES_PER_STEP, DEPTH = 1920, 1080, 16, 10
+STRIP_H = 8
+
+
+def algorithmic_bytes(stats, n_instances):
+    """Bytes the reference's own data structures would move for this work:
+    per box test one 48-byte Bvh node (hit.rs:77), per internal visit the two
+    child nodes peeked at, 2 x 32 bytes of box (hit.rs:90-91), per triangle test
+    a 12-byte index triple plus three 16-byte vertices (hit.rs:57-60), per ray
+    segment one 80-byte Instance per instance (trace.rs:77) and 56 bytes of ray
+    state and hit record, per pixel sample a 16-byte accumulator read and write."""
+    return (48 * stats["box_tests"] + 64 * stats["internal_visits"] + 60 * stats["triangle_tests"]
+            + (80 * n_instances + 56) * stats["rays"] + 32 * stats["paths"])
+
+
+def cpu_baseline(scene, cam, budget_s=12.0):
+    """The CPU oracle (a port of the reference's arithmetic: the reference itself has
+    no CPU path and no Rust toolchain exists here) on the same scene and seeds,
+    timed on this box's host cores on a bounded sample: whole 1080p frames of the
+    same chained sequence until the budget is spent."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+
+    cores = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16") or 16), 16)
+    r = O.OracleRenderer(scene, cam, trig=O.TRIG_DET, threads=cores)
+    frames, t0 = 0, time.perf_counter()
+    while True:
+        r.render(1)
+        frames += 1
+        dt = time.perf_counter() - t0
+        if dt > budget_s or frames >= FRAMES_PER_STEP:
+            break
+    s = r.stats_dict()
+    return {"value": s["rays"] / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "sample": f"{frames} full {WIDTH}x{HEIGHT} one-sample frames of the same scene, camera and seed chain "
+                      f"({s['rays']} rays in {dt:.2f} s)"}, r
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--grid", type=int, default=700, help="terrain grid resolution (700 -> ~1.0 M triangles)")
+    ap.add_argument("--pipeline", type=int, default=2, help="kernel variant: 0 nested loops, 1 per-lane state machine")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the trace path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from ray_tracing_amd import App, RT_OPT_COUNTERS, RT_OPT_PIPELINE, terrain_scene
+    from ray_tracing_amd import _lib as L
+
+    threads = min(os.cpu_count() or 1, 16)
+    scene, cam0 = terrain_scene(WIDTH, HEIGHT, n=args.grid, depth=DEPTH, threads=max(1, threads // max(1, world)))
+    n_inst = int(scene.info.num_instances)
+
+    def fresh_cam():
+        return L.CamData.from_buffer_copy(cam0)
+
+    stream = torch.cuda.current_stream().cuda_stream
+    app = App.create(fresh_cam(), scene, device=local_rank, stream=stream)
+    app.set_rows(STRIP_H, rank, world)
+    app.set_option(RT_OPT_PIPELINE, args.pipeline)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def one_step():
+        # a step = the whole 16-sample job from a zeroed accumulator
+        app.cam_data = fresh_cam()
+        app.render_frames(FRAMES_PER_STEP)
+
+    # --- counter pass (untimed): the reference's debug counters for one step --------------
+    app.set_option(RT_OPT_COUNTERS, 1)
+    app.reset_stats()
+    one_step()
+    app.synchronize()
+    counted = app.stats()
+    app.set_option(RT_OPT_COUNTERS, 0)
+
+    for _ in range(args.warmup):
+        one_step()
+    sync()
+    app.reset_stats()
+    kernel_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+        kernel_ms.append(None)
+    sync()
+    elapsed = time.perf_counter() - t0
+    # HIP-event time of the last launch on its own stream; all launches of the timed region
+    # are identical, and the region's wall time divided by K bounds it from above
+    last_ms = app.last_render_ms()
+    stats = app.stats()
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    r = torch.tensor([float(stats["rays"]), float(algorithmic_bytes(counted, n_inst)), last_ms],
+                     dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        rmax = r.clone()
+        dist.all_reduce(r, op=dist.ReduceOp.SUM)
+        dist.all_reduce(rmax, op=dist.ReduceOp.MAX)
+    else:
+        rmax = r
+    elapsed = float(t.item())
+    total_rays = float(r[0].item())
+    ms_per_step = elapsed / args.steps * 1e3
+
+    out = None
+    if rank == 0:
+        # roofline of the one kernel of the step, on this rank's share of the work
+        rank_bytes = float(algorithmic_bytes(counted, n_inst))
+        kernel_s = last_ms * 1e-3
+        achieved = rank_bytes / kernel_s / 1e9
+        out = {
+            "metric": "Mrays/s (primary+secondary)", "value": total_rays / elapsed / 1e6, "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "ms_per_frame": ms_per_step / FRAMES_PER_STEP,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"procedural terrain, {scene.n_triangles} triangles, {WIDTH}x{HEIGHT}, "
+                                   f"{FRAMES_PER_STEP} spp per step, depth {DEPTH}, 3 instances "
+                                   f"(glass / diffuse / emissive), reference-semantics BVH",
+                       "partition": f"interleaved {STRIP_H}-row strips over {world} GPU(s), no collective",
+                       "rays_per_step": total_rays / args.steps},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "path_kernel", "kernel_ms": last_ms,
+                         "algorithmic_bytes_per_launch": rank_bytes,
+                         "counters_per_launch": counted},
+        }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"], _ = cpu_baseline(scene, fresh_cam())
+    app.destroy()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -44,8 +44,9 @@ struct alignas(64) DevTri {
     float d;     float pad[3];
 };
 
-struct alignas(32) DevObject {
+struct alignas(64) DevObject {
     DevChild root;  // the object's root box and what the root is
+    DevChild unused;  // pads the record to the 64 bytes of a DevNode
 };
 
 struct alignas(16) DevInstance {

@@ -137,6 +137,7 @@ bool build_gpu_scene(const rt_scene_info& info, const rt_vertex* vertices, size_
     }
 
     out.objects.resize(n_objects);
+    std::memset(out.objects.data(), 0, n_objects * sizeof(DevObject));
     out.max_depth = 0;
     for (size_t i = 0; i < n_objects; ++i) {
         if (!make_child(bvh, n_bvh, n_triangles, dense, objects[i].bvh_root, out.objects[i].root, err)) return false;

@@ -42,7 +42,7 @@ struct rt_ctx {
     DevStats* d_stats = nullptr;
 
     // options
-    int pipeline = 0;
+    int pipeline = 3;
     bool probe_hits = false;
     bool counters = false;
     bool present = true;
@@ -189,7 +189,7 @@ int render(rt_ctx* c, const rt_cam_data& cam, uint32_t n_frames) {
     const uint32_t stack_needed = c->max_depth > 1 ? c->max_depth - 1 : 1;
 
     RT_HIP(c, hipEventRecord(c->ev0, c->stream));
-    RT_HIP(c, launch_path_kernel(sc, dc, rows, fr, n_frames, stack_needed, count, c->stream));
+    RT_HIP(c, launch_path_kernel(sc, dc, rows, fr, n_frames, stack_needed, count, c->pipeline, c->stream));
     RT_HIP(c, hipEventRecord(c->ev1, c->stream));
     c->timed = true;
     return RT_OK;
@@ -249,7 +249,7 @@ int rt_set_option(rt_ctx* c, int option, int64_t value) {
     if (!c) return RT_ERR_INVALID;
     switch (option) {
         case RT_OPT_PIPELINE:
-            if (value != 0) return fail(c, RT_ERR_INVALID, "unknown pipeline");
+            if (value < 0 || value > 3) return fail(c, RT_ERR_INVALID, "unknown pipeline");
             c->pipeline = (int)value;
             return RT_OK;
         case RT_OPT_PROBE_HITS: c->probe_hits = value != 0; return RT_OK;

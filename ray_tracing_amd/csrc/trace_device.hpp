@@ -457,11 +457,11 @@ RT_DEV void closest_hit(const DevScene& sc, Ray& self, HitRecord& record, uint32
 }
 
 // ---- accumulate + present: shader/src/lib.rs:71-108 ------------------------------------
-RT_DEV void accumulate(const DevCam& cam, float4 prev, V3 c, float4& acc_out, float4& present_out) {
+RT_DEV void accumulate(float frames_without_move, float4 prev, V3 c, float4& acc_out, float4& present_out) {
     bool nan = c.x > 1000.0f || c.y > 1000.0f || c.z > 1000.0f;
     float4 rendered = make_float4(c.x, c.y, c.z, 1.0f);
     float4 new_color;
-    if (cam.frames_without_move < 0.5f) {
+    if (frames_without_move < 0.5f) {
         acc_out = rendered;
         new_color = rendered;
     } else {
@@ -472,11 +472,16 @@ RT_DEV void accumulate(const DevCam& cam, float4 prev, V3 c, float4& acc_out, fl
             acc_color = make_float4(prev.x + rendered.x, prev.y + rendered.y, prev.z + rendered.z, prev.w + rendered.w);
         }
         acc_out = acc_color;
-        float div = cam.frames_without_move + 1.0f;
+        float div = frames_without_move + 1.0f;
         new_color = make_float4(acc_color.x / div, acc_color.y / div, acc_color.z / div, acc_color.w / div);
     }
+    // gamma 1/2.2 is only evaluated by the caller when the frame is presented
+    present_out = new_color;
+}
+
+RT_DEV float4 gamma_correct(float4 c) {
     const float g = 1.0f / 2.2f;
-    present_out = make_float4(powf(new_color.x, g), powf(new_color.y, g), powf(new_color.z, g), 1.0f);
+    return make_float4(powf(c.x, g), powf(c.y, g), powf(c.z, g), 1.0f);
 }
 
 }  // namespace dev

@@ -16,7 +16,7 @@ import pytest
 
 import oracle_lib as O
 from ray_tracing_amd import (App, RT_DEBUG_BVH_INTERSECTION, RT_DEBUG_TRIANGLE_INTERSECTION, RT_OPT_COUNTERS,
-                             RT_OPT_PROBE_HITS, default_scene)
+                             RT_OPT_PIPELINE, RT_OPT_PROBE_HITS, default_scene)
 from ray_tracing_amd import _lib as L
 
 pytestmark = pytest.mark.gpu
@@ -26,11 +26,12 @@ def copy_cam(cam):
     return L.CamData.from_buffer_copy(cam)
 
 
-def gpu_render(scene, cam, frames, counters=True, materials=None):
+def gpu_render(scene, cam, frames, counters=True, materials=None, pipeline=1):
     app = App.create(copy_cam(cam), scene, device=0)
     try:
         app.set_option(RT_OPT_PROBE_HITS, 1)
         app.set_option(RT_OPT_COUNTERS, int(counters))
+        app.set_option(RT_OPT_PIPELINE, pipeline)
         if materials is not None:
             app.set_materials(materials)
         app.render_frames(frames)
@@ -53,10 +54,12 @@ def c1():
     return default_scene(640, 360)
 
 
-def test_default_scene_primary_hits_bit_exact(c1):
-    """Config 1: the reference's default scene at 640x360, frame 0, zeroed accumulator."""
+@pytest.mark.parametrize("pipeline", [0, 1, 2, 3])
+def test_default_scene_primary_hits_bit_exact(c1, pipeline):
+    """Config 1: the reference's default scene at 640x360, frame 0, zeroed accumulator.
+    Both kernel variants (plain nested loops, per-lane state machine)."""
     scene, cam = c1
-    g = gpu_render(scene, cam, 1)
+    g = gpu_render(scene, cam, 1, pipeline=pipeline)
     ref = O.OracleRenderer(scene, cam, trig=O.TRIG_DET).render(1)
     tri, inst, tb = g["hits"]
     assert_bits_equal(tri, ref.hit_triangle, "triangle_id")
@@ -68,11 +71,12 @@ def test_default_scene_primary_hits_bit_exact(c1):
     assert g["stats"] == ref.stats_dict()
 
 
-def test_default_scene_radiance_bit_exact_over_frames(c1):
+@pytest.mark.parametrize("pipeline", [0, 1, 2, 3])
+def test_default_scene_radiance_bit_exact_over_frames(c1, pipeline):
     """Four chained frames: every later seed hashes the previous accumulator bits
     (lib.rs:57-60), so a single differing bit anywhere would show."""
     scene, cam = c1
-    g = gpu_render(scene, cam, 4)
+    g = gpu_render(scene, cam, 4, pipeline=pipeline)
     ref = O.OracleRenderer(scene, cam, trig=O.TRIG_DET).render(4)
     assert_bits_equal(g["acc"], ref.acc, "accumulator")
     np.testing.assert_allclose(g["present"], ref.present, rtol=1e-5, atol=1e-7)
