@@ -73,7 +73,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--grid", type=int, default=700, help="terrain grid resolution (700 -> ~1.0 M triangles)")
-    ap.add_argument("--pipeline", type=int, default=2, help="kernel variant: 0 nested loops, 1 per-lane state machine")
+    ap.add_argument("--pipeline", type=int, default=1, help="kernel: 0 plain nested loops, 1 persistent state machine")
     args = ap.parse_args()
 
     import torch

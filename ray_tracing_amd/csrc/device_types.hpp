@@ -94,6 +94,15 @@ struct DevStats {
     unsigned long long rays, box_tests, internal_visits, triangle_tests, paths;
 };
 
+// Work queues of the persistent kernel: 8 ranges of 64-pixel items (8x8 tiles),
+// one per XCD group, each with a head counter on a cache line of its own.
+struct DevQueue {
+    uint32_t* head;          // 8 counters, 32 words apart; zeroed before every launch
+    uint32_t first_item[9];  // queue i covers items [first_item[i], first_item[i + 1])
+    uint32_t tiles_x;        // 8x8 tiles per row of tiles
+    int w_ctl, w_box, w_leaf;  // vote weights of the three kinds of step
+};
+
 struct DevFrame {
     float* acc;      // W*H*4
     float* present;  // W*H*4

@@ -10,8 +10,8 @@ using namespace dev;
 
 namespace {
 
-constexpr int kBlock = 256;  // 4 waves; each wave owns an 8x8 pixel tile
-constexpr int kTileW = 32;   // block tile: 32 x 8 pixels
+constexpr int kBlock = 256;  // 4 waves
+constexpr int kTileW = 32;   // plain kernel: block tile 32 x 8 pixels, one 8x8 tile per wave
 constexpr int kTileH = 8;
 
 // Sum over the 64 lanes of a wave; the total is valid in lane 0.
@@ -39,14 +39,36 @@ __device__ __forceinline__ uint32_t global_row(const DevRows& rows, uint32_t ly)
     return (s * rows.world + rows.rank) * rows.strip_h + o;
 }
 
+__device__ __forceinline__ void flush_stats(const DevFrame& fr, bool count, uint32_t lane, unsigned long long n_rays,
+                                            unsigned long long n_paths, unsigned long long n_box,
+                                            unsigned long long n_internal, unsigned long long n_tri) {
+    n_rays = wave_sum(n_rays);
+    n_paths = wave_sum(n_paths);
+    if (count) {
+        n_box = wave_sum(n_box);
+        n_internal = wave_sum(n_internal);
+        n_tri = wave_sum(n_tri);
+    }
+    if (lane == 0 && fr.stats) {
+        atomicAdd(&fr.stats->rays, n_rays);
+        atomicAdd(&fr.stats->paths, n_paths);
+        if (count) {
+            atomicAdd(&fr.stats->box_tests, n_box);
+            atomicAdd(&fr.stats->internal_visits, n_internal);
+            atomicAdd(&fr.stats->triangle_tests, n_tri);
+        }
+    }
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------
-// Whole-path kernel: the shape of the reference's shader::main
+// Plain whole-path kernel: the shape of the reference's shader::main
 // (shader/src/lib.rs:23-109).  One lane = one pixel = `n_frames` consecutive
 // one-sample frames of that pixel; the accumulator value stays in registers
 // between them (a pixel's frame k+1 depends only on its own frame k through
-// the seed, lib.rs:57-60) and is written once.
+// the seed, lib.rs:57-60) and is written once.  Kept as the simplest correct
+// form; the persistent kernel below computes the same thing faster.
 // ---------------------------------------------------------------------------
 template <int STACK_N, bool COUNT>
 __global__ __launch_bounds__(kBlock) void path_kernel(DevScene sc, DevCam cam, DevRows rows, DevFrame fr,
@@ -67,7 +89,7 @@ __global__ __launch_bounds__(kBlock) void path_kernel(DevScene sc, DevCam cam, D
         uint32_t* stack = &s_stack[threadIdx.x];
         const uint32_t idx = x + y * cam.W;
         float4 acc = reinterpret_cast<const float4*>(fr.acc)[idx];
-        float4 present = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+        float4 shown = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
         HitRecord first;
         record_new(first);
 
@@ -100,7 +122,7 @@ __global__ __launch_bounds__(kBlock) void path_kernel(DevScene sc, DevCam cam, D
             if (!finished) color = v3(0.0f, 0.0f, 0.0f);  // trace.rs:204-205
             n_paths += 1;
             float4 next_acc;
-            accumulate(cam.frames_without_move, acc, color, next_acc, present);
+            accumulate(cam.frames_without_move, acc, color, next_acc, shown);
             acc = next_acc;
             // the event loop's bookkeeping between frames, main.rs:147-148
             cam.frame += 1u;
@@ -108,7 +130,7 @@ __global__ __launch_bounds__(kBlock) void path_kernel(DevScene sc, DevCam cam, D
         }
 
         reinterpret_cast<float4*>(fr.acc)[idx] = acc;
-        if (fr.present) reinterpret_cast<float4*>(fr.present)[idx] = gamma_correct(present);
+        if (fr.present) reinterpret_cast<float4*>(fr.present)[idx] = gamma_correct(shown);
         if (fr.hit_triangle) {
             fr.hit_triangle[idx] = first.triangle_id;
             fr.hit_instance[idx] = first.instance_id;
@@ -119,70 +141,57 @@ __global__ __launch_bounds__(kBlock) void path_kernel(DevScene sc, DevCam cam, D
             fr.triangle_tests[idx] = first.triangle_tests;
         }
     }
-
-    n_rays = wave_sum(n_rays);
-    n_paths = wave_sum(n_paths);
-    if (COUNT) {
-        n_box = wave_sum(n_box);
-        n_internal = wave_sum(n_internal);
-        n_tri = wave_sum(n_tri);
-    }
-    if (lane == 0 && fr.stats) {
-        atomicAdd(&fr.stats->rays, n_rays);
-        atomicAdd(&fr.stats->paths, n_paths);
-        if (COUNT) {
-            atomicAdd(&fr.stats->box_tests, n_box);
-            atomicAdd(&fr.stats->internal_visits, n_internal);
-            atomicAdd(&fr.stats->triangle_tests, n_tri);
-        }
-    }
+    flush_stats(fr, COUNT, lane, n_rays, n_paths, n_box, n_internal, n_tri);
 }
 
 // ---------------------------------------------------------------------------
-// Scheduled whole-path kernel.  Same per-lane work, in the same per-lane order,
-// as path_kernel above -- but no lane ever waits at the end of a frame, a
-// segment or an instance for the other 63.  Each lane is a small state machine:
+// Persistent whole-path kernel.
 //
-//   CONTROL  it needs its next piece of work: a new path (generate), the next
-//            segment, the next instance of the current segment (extend set-up),
-//            or, after the last instance, shading and accumulation;
-//   BOX      it holds a child box to test (the node on top of the reference's
-//            stack) and keeps descending / popping until it owns a leaf;
-//   LEAF     it holds a triangle range to test;
-//   DEAD     all frames of its pixel are done.
+// Same per-lane work, in the same per-lane order, as path_kernel -- so the
+// results are identical -- but scheduled for 64-wide waves:
 //
-// The wave loops over "control step for whoever needs one; box steps until no
-// lane is in BOX; one leaf for whoever holds one".  A wave therefore always
-// runs each of the three code regions with as many lanes as are ready for it.
+//  * Each lane is a small state machine that owns ONE pending 64-byte item (an
+//    internal node, the parent node of a popped child, an object's root record
+//    or a triangle).  The load of the item is issued at the end of one step and
+//    consumed by the next, so a lane never has two dependent fetches in a step.
+//  * A step is one of three kinds: CONTROL (generate a path, start a segment,
+//    set up the next instance, or shade + accumulate after the last instance),
+//    BOX (test the child box on top of the reference's stack, descend or pop)
+//    and LEAF (test one triangle).  Per iteration the wave runs only the kind
+//    most of its lanes are waiting for; the others keep their item and wait.
+//    No lane ever idles until its neighbours finish a leaf, a subtree, an
+//    instance, a bounce or a frame.
+//  * Waves are persistent: a lane whose pixel has had all its frames pulls the
+//    next pixel from a work queue, so lanes never retire early.  There is one
+//    queue per XCD group (workgroups with equal blockIdx % 8 share an L2), each
+//    covering a contiguous range of 8x8 pixel tiles; a wave that drains its own
+//    queue moves on to the next one.
 // ---------------------------------------------------------------------------
-enum : uint32_t { PH_CONTROL = 0, PH_BOX = 1, PH_LEAF = 2, PH_DEAD = 3 };
-enum : uint32_t { CT_NEW_PATH = 0, CT_START_SEGMENT = 1, CT_NEXT_INSTANCE = 2 };
+enum : uint32_t { ST_CONTROL = 0, ST_DESC = 1, ST_POP = 2, ST_LEAF = 3, ST_DEAD = 4 };
+enum : uint32_t { CT_NEW_PIXEL = 0, CT_NEW_PATH = 1, CT_START_SEGMENT = 2, CT_NEXT_INSTANCE = 3 };
 
 template <int STACK_N, bool COUNT>
-__global__ __launch_bounds__(kBlock) void path_kernel_sched(DevScene sc, DevCam cam, DevRows rows, DevFrame fr,
-                                                            uint32_t n_frames, uint32_t tiles_x, uint32_t n_tiles) {
+__global__ __launch_bounds__(kBlock) void path_kernel_persistent(DevScene sc, DevCam cam, DevRows rows, DevFrame fr,
+                                                                 DevQueue q, uint32_t n_frames) {
     __shared__ uint32_t s_stack[STACK_N * kBlock];
 
-    const uint32_t tile = xcd_remap(blockIdx.x, n_tiles);
-    const uint32_t tile_y = tile / tiles_x, tile_x = tile - tile_y * tiles_x;
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t x = tile_x * kTileW + wave * 8u + (lane & 7u);
-    const uint32_t ly = tile_y * kTileH + (lane >> 3);
-    const uint32_t y = global_row(rows, ly);
-    const bool valid = x < cam.W && ly < rows.local_rows && y < cam.H && n_frames > 0;
-    const uint32_t idx = valid ? x + y * cam.W : 0u;
+    const uint32_t lane = threadIdx.x & 63u;
     uint32_t* const stack = &s_stack[threadIdx.x];
+    const unsigned long long lanes_below = (1ull << lane) - 1ull;
 
     unsigned long long n_rays = 0, n_box = 0, n_internal = 0, n_tri = 0, n_paths = 0;
 
-    uint32_t phase = valid ? PH_CONTROL : PH_DEAD;
-    uint32_t ctl = CT_NEW_PATH;
-    // path state
-    float4 acc = valid ? reinterpret_cast<const float4*>(fr.acc)[idx] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    uint32_t phase = n_frames > 0 ? ST_CONTROL : ST_DEAD;
+    uint32_t ctl = CT_NEW_PIXEL;
+    uint32_t queues_tried = 0;  // wave-uniform: how many queues this wave has found empty
+    // pixel state
+    uint32_t x = 0, y = 0, idx = 0;
+    float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     float4 shown = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
     uint32_t frame = cam.frame;
     float fwm = cam.frames_without_move;
-    uint32_t frames_left = n_frames;
+    uint32_t frames_left = 0;
+    // path state
     uint32_t seed = 0, seg = 0, inst = 0;
     V3 color = v3(1.0f, 1.0f, 1.0f);
     Ray ray;
@@ -194,509 +203,125 @@ __global__ __launch_bounds__(kBlock) void path_kernel_sched(DevScene sc, DevCam 
     V3 lpos = ray.pos, ldir = ray.dir;
     float t_hi = RT_INF;
     bool cull = false;
-    float4 lo = make_float4(0.0f, 0.0f, 0.0f, 0.0f), hi = lo;
-    uint32_t a = 0, b = 0, sp = 0;
-
-    while (phase != PH_DEAD) {
-        // ------------------------------ CONTROL ------------------------------
-        if (phase == PH_CONTROL) {
-            for (;;) {
-                if (ctl == CT_NEW_PATH) {
-                    // shader/src/lib.rs:57-69 and Ray::get_color, trace.rs:175-191
-                    seed = get_seed(frame, x, y, acc.x, acc.y, acc.z);
-                    color = v3(1.0f, 1.0f, 1.0f);
-                    float jx = rand_float(seed, 0.0f, 1.0f);
-                    float jy = rand_float(seed, 0.0f, 1.0f);
-                    ray = camera_ray(cam, (float)x + jx, (float)y + jy);
-                    ray.dir = normalize(ray.dir);
-                    seg = 0;
-                    ctl = CT_START_SEGMENT;
-                }
-                if (ctl == CT_START_SEGMENT) {
-                    // head of Ray::trace_ray, trace.rs:73-74
-                    ray.dir = normalize(ray.dir);
-                    record_new(rec);
-                    inst = 0;
-                    n_rays += 1;
-                    ctl = CT_NEXT_INSTANCE;
-                }
-                if (inst < sc.n_instances) {
-                    // trace.rs:76-94
-                    const DevInstance& in = sc.instances[inst];
-                    lpos = xf_point(in.inv, ray.pos);
-                    ldir = xf_vector(in.inv, ray.dir);
-                    t_hi = rec.t;
-                    cull = in.cull != 0u;
-                    const float4* rp = reinterpret_cast<const float4*>(&sc.objects[in.object_id].root);
-                    lo = rp[0];
-                    hi = rp[1];
-                    sp = 0;
-                    phase = PH_BOX;
-                    break;
-                }
-                // every instance has been visited: the rest of trace_ray, trace.rs:97-172
-                if (seg == 0 && fr.hit_triangle) {
-                    fr.hit_triangle[idx] = rec.triangle_id;
-                    fr.hit_instance[idx] = rec.instance_id;
-                    fr.hit_t_bits[idx] = __float_as_uint(rec.t);
-                }
-                if (COUNT) {
-                    if (seg == 0 && fr.box_tests) {
-                        fr.box_tests[idx] = rec.box_tests;
-                        fr.triangle_tests[idx] = rec.triangle_tests;
-                    }
-                    n_box += rec.box_tests;
-                    n_internal += rec.internal_visits;
-                    n_tri += rec.triangle_tests;
-                }
-                int state = shade(sc, cam, rec, ray, seed, color);
-                seg += 1;
-                if (state == STATE_RAY && seg < cam.depth) {
-                    ctl = CT_START_SEGMENT;
-                    continue;
-                }
-                if (state == STATE_RAY) color = v3(0.0f, 0.0f, 0.0f);  // never finished bouncing, trace.rs:204-205
-                // shader/src/lib.rs:71-98, then the event loop's bookkeeping, main.rs:147-148
-                float4 next_acc;
-                accumulate(fwm, acc, color, next_acc, shown);
-                acc = next_acc;
-                n_paths += 1;
-                frame += 1u;
-                fwm += 1.0f;
-                frames_left -= 1u;
-                if (frames_left == 0u) {
-                    reinterpret_cast<float4*>(fr.acc)[idx] = acc;
-                    if (fr.present) reinterpret_cast<float4*>(fr.present)[idx] = gamma_correct(shown);
-                    phase = PH_DEAD;
-                    break;
-                }
-                ctl = CT_NEW_PATH;
-            }
-        }
-        // -------------------------------- BOX --------------------------------
-        while (phase == PH_BOX) {
-            // the one place a box is tested: the node on top of the reference's stack (hit.rs:77-86)
-            if (COUNT) rec.box_tests += 1;
-            const bool alive = !culled(hits_bounding(lpos, ldir, lo, hi), t_hi);
-            a = __float_as_uint(lo.w);
-            b = __float_as_uint(hi.w);
-            if (alive) {
-                if (b != kInternalTag) {
-                    phase = PH_LEAF;
-                } else {
-                    // internal node: near/far rule of hit.rs:88-107
-                    const float4* np = reinterpret_cast<const float4*>(&sc.nodes[a]);
-                    float4 lo1 = np[0], hi1 = np[1], lo2 = np[2], hi2 = np[3];
-                    V3 c1 = (v3(lo1.x, lo1.y, lo1.z) + v3(hi1.x, hi1.y, hi1.z)) * 0.5f;
-                    V3 c2 = (v3(lo2.x, lo2.y, lo2.z) + v3(hi2.x, hi2.y, hi2.z)) * 0.5f;
-                    V3 e1 = c1 - lpos, e2 = c2 - lpos;
-                    bool first_is_1 = dot(e1, e1) < dot(e2, e2);
-                    if (COUNT) rec.internal_visits += 1;
-                    stack[sp * kBlock] = (a << 1) | (first_is_1 ? 1u : 0u);  // the farther child's slot
-                    sp += 1;
-                    lo = first_is_1 ? lo1 : lo2;
-                    hi = first_is_1 ? hi1 : hi2;
-                }
-            } else if (sp == 0) {
-                inst += 1;  // this instance is finished (hit.rs:76)
-                ctl = CT_NEXT_INSTANCE;
-                phase = PH_CONTROL;
-            } else {
-                sp -= 1;
-                uint32_t ref = stack[sp * kBlock];
-                const float4* cp = reinterpret_cast<const float4*>(&sc.nodes[ref >> 1].c[ref & 1]);
-                lo = cp[0];
-                hi = cp[1];
-            }
-        }
-        // -------------------------------- LEAF -------------------------------
-        if (phase == PH_LEAF) {
-            // `for i in first..=last`, hit.rs:111-121
-            if (a <= b) {
-                uint32_t i = a;
-                for (;;) {
-                    const float4* tp = reinterpret_cast<const float4*>(&sc.tris[i]);
-                    float4 ta = tp[0], tb = tp[1], tc = tp[2];
-                    float td = tp[3].x;
-                    float t = triangle_ray_intersect(ta, tb, tc, td, lpos, ldir, kEps, t_hi, cull);
-                    if (!is_inf_bits(t)) {
-                        t_hi = t;
-                        rec.t = t;
-                        rec.triangle_id = i;
-                        rec.instance_id = inst;
-                    }
-                    if (i == b) break;
-                    i += 1;
-                }
-            }
-            if (COUNT) rec.triangle_tests += b - a + 1;
-            if (sp == 0) {
-                inst += 1;
-                ctl = CT_NEXT_INSTANCE;
-                phase = PH_CONTROL;
-            } else {
-                sp -= 1;
-                uint32_t ref = stack[sp * kBlock];
-                const float4* cp = reinterpret_cast<const float4*>(&sc.nodes[ref >> 1].c[ref & 1]);
-                lo = cp[0];
-                hi = cp[1];
-                phase = PH_BOX;
-            }
-        }
-    }
-
-    n_rays = wave_sum(n_rays);
-    n_paths = wave_sum(n_paths);
-    if (COUNT) {
-        n_box = wave_sum(n_box);
-        n_internal = wave_sum(n_internal);
-        n_tri = wave_sum(n_tri);
-    }
-    if (lane == 0 && fr.stats) {
-        atomicAdd(&fr.stats->rays, n_rays);
-        atomicAdd(&fr.stats->paths, n_paths);
-        if (COUNT) {
-            atomicAdd(&fr.stats->box_tests, n_box);
-            atomicAdd(&fr.stats->internal_visits, n_internal);
-            atomicAdd(&fr.stats->triangle_tests, n_tri);
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------
-// One-step-per-iteration whole-path kernel.  Every lane owns exactly one
-// pending 64-byte ITEM (an internal node, the parent node of a popped child,
-// an object's root record, or a triangle) whose load was issued at the end of
-// the previous iteration.  In each iteration a lane consumes its item with one
-// step of the matching kind -- box step, triangle step or control step -- and
-// issues the load of its next item.  No lane ever waits for another lane's
-// leaf or subtree to finish, and the single load per iteration is always one
-// iteration ahead of its use.  Per-lane order of operations is exactly that of
-// path_kernel, so results are identical.
-// ---------------------------------------------------------------------------
-enum : uint32_t { ST_CONTROL = 0, ST_DESC = 1, ST_POP = 2, ST_LEAF = 3, ST_DEAD = 4 };
-
-template <int STACK_N, bool COUNT>
-__global__ __launch_bounds__(kBlock) void path_kernel_step(DevScene sc, DevCam cam, DevRows rows, DevFrame fr,
-                                                           uint32_t n_frames, uint32_t tiles_x, uint32_t n_tiles) {
-    __shared__ uint32_t s_stack[STACK_N * kBlock];
-
-    const uint32_t tile = xcd_remap(blockIdx.x, n_tiles);
-    const uint32_t tile_y = tile / tiles_x, tile_x = tile - tile_y * tiles_x;
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t x = tile_x * kTileW + wave * 8u + (lane & 7u);
-    const uint32_t ly = tile_y * kTileH + (lane >> 3);
-    const uint32_t y = global_row(rows, ly);
-    const bool valid = x < cam.W && ly < rows.local_rows && y < cam.H && n_frames > 0;
-    const uint32_t idx = valid ? x + y * cam.W : 0u;
-    uint32_t* const stack = &s_stack[threadIdx.x];
-
-    unsigned long long n_rays = 0, n_box = 0, n_internal = 0, n_tri = 0, n_paths = 0;
-
-    uint32_t phase = valid ? ST_CONTROL : ST_DEAD;
-    uint32_t ctl = CT_NEW_PATH;
-    float4 acc = valid ? reinterpret_cast<const float4*>(fr.acc)[idx] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    float4 shown = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
-    uint32_t frame = cam.frame;
-    float fwm = cam.frames_without_move;
-    uint32_t frames_left = n_frames;
-    uint32_t seed = 0, seg = 0, inst = 0;
-    V3 color = v3(1.0f, 1.0f, 1.0f);
-    Ray ray;
-    ray.pos = v3(0.0f, 0.0f, 0.0f);
-    ray.dir = v3(0.0f, 0.0f, 1.0f);
-    HitRecord rec;
-    record_new(rec);
-    V3 lpos = ray.pos, ldir = ray.dir;
-    float t_hi = RT_INF;
-    bool cull = false;
     float4 it0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), it1 = it0, it2 = it0, it3 = it0;  // the pending item
-    uint32_t node = 0;     // ST_DESC: index of the node held in the item
-    uint32_t slot = 0;     // ST_POP: which child of the item is meant
+    uint32_t node = 0;  // ST_DESC: index of the node held in the item
+    uint32_t slot = 0;  // ST_POP: which child of the item is meant
     uint32_t tri_i = 0, tri_last = 0, sp = 0;
 
     while (phase != ST_DEAD) {
         const float4* next = nullptr;
-        if (phase == ST_CONTROL) {
-            for (;;) {
-                if (ctl == CT_NEW_PATH) {
-                    seed = get_seed(frame, x, y, acc.x, acc.y, acc.z);
-                    color = v3(1.0f, 1.0f, 1.0f);
-                    float jx = rand_float(seed, 0.0f, 1.0f);
-                    float jy = rand_float(seed, 0.0f, 1.0f);
-                    ray = camera_ray(cam, (float)x + jx, (float)y + jy);
-                    ray.dir = normalize(ray.dir);
-                    seg = 0;
-                    ctl = CT_START_SEGMENT;
-                }
-                if (ctl == CT_START_SEGMENT) {
-                    ray.dir = normalize(ray.dir);
-                    record_new(rec);
-                    inst = 0;
-                    n_rays += 1;
-                    ctl = CT_NEXT_INSTANCE;
-                }
-                if (inst < sc.n_instances) {
-                    const DevInstance& in = sc.instances[inst];
-                    lpos = xf_point(in.inv, ray.pos);
-                    ldir = xf_vector(in.inv, ray.dir);
-                    t_hi = rec.t;
-                    cull = in.cull != 0u;
-                    next = reinterpret_cast<const float4*>(&sc.objects[in.object_id]);
-                    slot = 0;
-                    sp = 0;
-                    phase = ST_POP;
-                    break;
-                }
-                if (seg == 0 && fr.hit_triangle) {
-                    fr.hit_triangle[idx] = rec.triangle_id;
-                    fr.hit_instance[idx] = rec.instance_id;
-                    fr.hit_t_bits[idx] = __float_as_uint(rec.t);
-                }
-                if (COUNT) {
-                    if (seg == 0 && fr.box_tests) {
-                        fr.box_tests[idx] = rec.box_tests;
-                        fr.triangle_tests[idx] = rec.triangle_tests;
-                    }
-                    n_box += rec.box_tests;
-                    n_internal += rec.internal_visits;
-                    n_tri += rec.triangle_tests;
-                }
-                int state = shade(sc, cam, rec, ray, seed, color);
-                seg += 1;
-                if (state == STATE_RAY && seg < cam.depth) {
-                    ctl = CT_START_SEGMENT;
-                    continue;
-                }
-                if (state == STATE_RAY) color = v3(0.0f, 0.0f, 0.0f);
-                float4 next_acc;
-                accumulate(fwm, acc, color, next_acc, shown);
-                acc = next_acc;
-                n_paths += 1;
-                frame += 1u;
-                fwm += 1.0f;
-                frames_left -= 1u;
-                if (frames_left == 0u) {
-                    reinterpret_cast<float4*>(fr.acc)[idx] = acc;
-                    if (fr.present) reinterpret_cast<float4*>(fr.present)[idx] = gamma_correct(shown);
-                    phase = ST_DEAD;
-                    break;
-                }
-                ctl = CT_NEW_PATH;
-            }
-        } else {
-            bool finished = false;  // this lane has to pop (or the instance is done)
-            if (phase == ST_LEAF) {
-                // one triangle of `for i in first..=last`, hit.rs:111-121
-                float t = triangle_ray_intersect(it0, it1, it2, it3.x, lpos, ldir, kEps, t_hi, cull);
-                if (!is_inf_bits(t)) {
-                    t_hi = t;
-                    rec.t = t;
-                    rec.triangle_id = tri_i;
-                    rec.instance_id = inst;
-                }
-                if (COUNT) rec.triangle_tests += 1;
-                if (tri_i == tri_last) {
-                    finished = true;
-                } else {
-                    tri_i += 1;
-                    next = reinterpret_cast<const float4*>(&sc.tris[tri_i]);
-                }
-            } else {
-                float4 lo, hi;
-                if (phase == ST_DESC) {
-                    // the item is an internal node that passed its test: hit.rs:88-107
-                    V3 c1 = (v3(it0.x, it0.y, it0.z) + v3(it1.x, it1.y, it1.z)) * 0.5f;
-                    V3 c2 = (v3(it2.x, it2.y, it2.z) + v3(it3.x, it3.y, it3.z)) * 0.5f;
-                    V3 e1 = c1 - lpos, e2 = c2 - lpos;
-                    bool first_is_1 = dot(e1, e1) < dot(e2, e2);
-                    if (COUNT) rec.internal_visits += 1;
-                    stack[sp * kBlock] = (node << 1) | (first_is_1 ? 1u : 0u);  // the farther child's slot
-                    sp += 1;
-                    lo = first_is_1 ? it0 : it2;
-                    hi = first_is_1 ? it1 : it3;
-                } else {
-                    lo = slot ? it2 : it0;
-                    hi = slot ? it3 : it1;
-                }
-                // the node on top of the reference's stack: hit.rs:77-86
-                if (COUNT) rec.box_tests += 1;
-                const bool alive = !culled(hits_bounding(lpos, ldir, lo, hi), t_hi);
-                const uint32_t a = __float_as_uint(lo.w), b = __float_as_uint(hi.w);
-                if (!alive) {
-                    finished = true;
-                } else if (b == kInternalTag) {
-                    phase = ST_DESC;
-                    node = a;
-                    next = reinterpret_cast<const float4*>(&sc.nodes[a]);
-                } else if (a <= b) {
-                    phase = ST_LEAF;
-                    tri_i = a;
-                    tri_last = b;
-                    next = reinterpret_cast<const float4*>(&sc.tris[a]);
-                } else {
-                    finished = true;  // `first..=last` with nothing in it
-                }
-            }
-            if (finished) {
-                if (sp == 0) {
-                    inst += 1;  // this instance is done, trace.rs:76
-                    ctl = CT_NEXT_INSTANCE;
-                    phase = ST_CONTROL;
-                } else {
-                    sp -= 1;
-                    uint32_t ref = stack[sp * kBlock];
-                    slot = ref & 1u;
-                    phase = ST_POP;
-                    next = reinterpret_cast<const float4*>(&sc.nodes[ref >> 1]);
-                }
-            }
-        }
-        if (next) {
-            it0 = next[0];
-            it1 = next[1];
-            it2 = next[2];
-            it3 = next[3];
-        }
-    }
-
-    n_rays = wave_sum(n_rays);
-    n_paths = wave_sum(n_paths);
-    if (COUNT) {
-        n_box = wave_sum(n_box);
-        n_internal = wave_sum(n_internal);
-        n_tri = wave_sum(n_tri);
-    }
-    if (lane == 0 && fr.stats) {
-        atomicAdd(&fr.stats->rays, n_rays);
-        atomicAdd(&fr.stats->paths, n_paths);
-        if (COUNT) {
-            atomicAdd(&fr.stats->box_tests, n_box);
-            atomicAdd(&fr.stats->internal_visits, n_internal);
-            atomicAdd(&fr.stats->triangle_tests, n_tri);
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------
-// Voting variant of the one-step kernel: per iteration the wave runs only the
-// kind of step (control / box / triangle) that most of its lanes are waiting
-// for; lanes of the other kinds keep their pending item and sit the iteration
-// out.  The per-lane sequence of operations is unchanged.
-// ---------------------------------------------------------------------------
-template <int STACK_N, bool COUNT, int W_CTL, int W_BOX, int W_LEAF>
-__global__ __launch_bounds__(kBlock) void path_kernel_vote(DevScene sc, DevCam cam, DevRows rows, DevFrame fr,
-                                                           uint32_t n_frames, uint32_t tiles_x, uint32_t n_tiles) {
-    __shared__ uint32_t s_stack[STACK_N * kBlock];
-
-    const uint32_t tile = xcd_remap(blockIdx.x, n_tiles);
-    const uint32_t tile_y = tile / tiles_x, tile_x = tile - tile_y * tiles_x;
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t x = tile_x * kTileW + wave * 8u + (lane & 7u);
-    const uint32_t ly = tile_y * kTileH + (lane >> 3);
-    const uint32_t y = global_row(rows, ly);
-    const bool valid = x < cam.W && ly < rows.local_rows && y < cam.H && n_frames > 0;
-    const uint32_t idx = valid ? x + y * cam.W : 0u;
-    uint32_t* const stack = &s_stack[threadIdx.x];
-
-    unsigned long long n_rays = 0, n_box = 0, n_internal = 0, n_tri = 0, n_paths = 0;
-
-    uint32_t phase = valid ? ST_CONTROL : ST_DEAD;
-    uint32_t ctl = CT_NEW_PATH;
-    float4 acc = valid ? reinterpret_cast<const float4*>(fr.acc)[idx] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    float4 shown = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
-    uint32_t frame = cam.frame;
-    float fwm = cam.frames_without_move;
-    uint32_t frames_left = n_frames;
-    uint32_t seed = 0, seg = 0, inst = 0;
-    V3 color = v3(1.0f, 1.0f, 1.0f);
-    Ray ray;
-    ray.pos = v3(0.0f, 0.0f, 0.0f);
-    ray.dir = v3(0.0f, 0.0f, 1.0f);
-    HitRecord rec;
-    record_new(rec);
-    V3 lpos = ray.pos, ldir = ray.dir;
-    float t_hi = RT_INF;
-    bool cull = false;
-    float4 it0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), it1 = it0, it2 = it0, it3 = it0;  // the pending item
-    uint32_t node = 0;     // ST_DESC: index of the node held in the item
-    uint32_t slot = 0;     // ST_POP: which child of the item is meant
-    uint32_t tri_i = 0, tri_last = 0, sp = 0;
-
-    while (phase != ST_DEAD) {
-        const float4* next = nullptr;
-        // Wave-uniform choice of the ONE kind of step this iteration runs: the kind
-        // most lanes are waiting for (weights bias towards the cheaper code paths).
-        const int w_ctl = __popcll(__ballot(phase == ST_CONTROL)) * W_CTL;
-        const int w_box = __popcll(__ballot(phase == ST_DESC || phase == ST_POP)) * W_BOX;
-        const int w_leaf = __popcll(__ballot(phase == ST_LEAF)) * W_LEAF;
+        // wave-uniform choice of the one kind of step this iteration runs
+        const int w_ctl = __popcll(__ballot(phase == ST_CONTROL)) * q.w_ctl;
+        const int w_box = __popcll(__ballot(phase == ST_DESC || phase == ST_POP)) * q.w_box;
+        const int w_leaf = __popcll(__ballot(phase == ST_LEAF)) * q.w_leaf;
         const int pick = (w_box >= w_leaf && w_box >= w_ctl) ? 1 : (w_leaf >= w_ctl ? 2 : 0);
-        if (pick == 0 && phase == ST_CONTROL) {
-            for (;;) {
-                if (ctl == CT_NEW_PATH) {
-                    seed = get_seed(frame, x, y, acc.x, acc.y, acc.z);
-                    color = v3(1.0f, 1.0f, 1.0f);
-                    float jx = rand_float(seed, 0.0f, 1.0f);
-                    float jy = rand_float(seed, 0.0f, 1.0f);
-                    ray = camera_ray(cam, (float)x + jx, (float)y + jy);
-                    ray.dir = normalize(ray.dir);
-                    seg = 0;
-                    ctl = CT_START_SEGMENT;
-                }
-                if (ctl == CT_START_SEGMENT) {
-                    ray.dir = normalize(ray.dir);
-                    record_new(rec);
-                    inst = 0;
-                    n_rays += 1;
-                    ctl = CT_NEXT_INSTANCE;
-                }
-                if (inst < sc.n_instances) {
-                    const DevInstance& in = sc.instances[inst];
-                    lpos = xf_point(in.inv, ray.pos);
-                    ldir = xf_vector(in.inv, ray.dir);
-                    t_hi = rec.t;
-                    cull = in.cull != 0u;
-                    next = reinterpret_cast<const float4*>(&sc.objects[in.object_id]);
-                    slot = 0;
-                    sp = 0;
-                    phase = ST_POP;
-                    break;
-                }
-                if (seg == 0 && fr.hit_triangle) {
-                    fr.hit_triangle[idx] = rec.triangle_id;
-                    fr.hit_instance[idx] = rec.instance_id;
-                    fr.hit_t_bits[idx] = __float_as_uint(rec.t);
-                }
-                if (COUNT) {
-                    if (seg == 0 && fr.box_tests) {
-                        fr.box_tests[idx] = rec.box_tests;
-                        fr.triangle_tests[idx] = rec.triangle_tests;
+
+        if (pick == 0) {
+            // one queue per XCD group; every lane that needs a pixel takes part in one fetch
+            const bool want = phase == ST_CONTROL && ctl == CT_NEW_PIXEL;
+            const unsigned long long wm = __ballot(want);
+            if (wm != 0ull) {
+                const uint32_t n_want = (uint32_t)__popcll(wm);
+                const uint32_t qi = ((blockIdx.x & 7u) + queues_tried) & 7u;
+                const uint32_t q_first = q.first_item[qi], q_size = q.first_item[qi + 1] - q_first;
+                uint32_t base = 0;
+                if (lane == (uint32_t)__ffsll((long long)wm) - 1u) base = atomicAdd(&q.head[qi * 32u], n_want);
+                base = __shfl(base, __ffsll((long long)wm) - 1, 64);
+                if (base + n_want >= q_size) queues_tried += 1u;  // this queue is (about to be) empty
+                if (want) {
+                    const uint32_t k = base + (uint32_t)__popcll(wm & lanes_below);
+                    if (k < q_size) {
+                        const uint32_t item = q_first + k;
+                        const uint32_t tile = item >> 6, l = item & 63u;
+                        const uint32_t tile_y = tile / q.tiles_x, tile_x = tile - tile_y * q.tiles_x;
+                        x = tile_x * 8u + (l & 7u);
+                        const uint32_t ly = tile_y * 8u + (l >> 3);
+                        y = global_row(rows, ly);
+                        if (x < cam.W && ly < rows.local_rows && y < cam.H) {
+                            idx = x + y * cam.W;
+                            acc = reinterpret_cast<const float4*>(fr.acc)[idx];
+                            frame = cam.frame;
+                            fwm = cam.frames_without_move;
+                            frames_left = n_frames;
+                            ctl = CT_NEW_PATH;
+                        }
+                    } else if (queues_tried >= 8u) {
+                        phase = ST_DEAD;
                     }
-                    n_box += rec.box_tests;
-                    n_internal += rec.internal_visits;
-                    n_tri += rec.triangle_tests;
                 }
-                int state = shade(sc, cam, rec, ray, seed, color);
-                seg += 1;
-                if (state == STATE_RAY && seg < cam.depth) {
-                    ctl = CT_START_SEGMENT;
-                    continue;
+            }
+            if (phase == ST_CONTROL && ctl != CT_NEW_PIXEL) {
+                for (;;) {
+                    if (ctl == CT_NEW_PATH) {
+                        // shader/src/lib.rs:57-69 and Ray::get_color, trace.rs:175-191
+                        seed = get_seed(frame, x, y, acc.x, acc.y, acc.z);
+                        color = v3(1.0f, 1.0f, 1.0f);
+                        float jx = rand_float(seed, 0.0f, 1.0f);
+                        float jy = rand_float(seed, 0.0f, 1.0f);
+                        ray = camera_ray(cam, (float)x + jx, (float)y + jy);
+                        ray.dir = normalize(ray.dir);
+                        seg = 0;
+                        ctl = CT_START_SEGMENT;
+                    }
+                    if (ctl == CT_START_SEGMENT) {
+                        // head of Ray::trace_ray, trace.rs:73-74
+                        ray.dir = normalize(ray.dir);
+                        record_new(rec);
+                        inst = 0;
+                        n_rays += 1;
+                        ctl = CT_NEXT_INSTANCE;
+                    }
+                    if (inst < sc.n_instances) {
+                        // trace.rs:76-94: the ray in the instance's object space, clamp (EPS, record.t)
+                        const DevInstance& in = sc.instances[inst];
+                        lpos = xf_point(in.inv, ray.pos);
+                        ldir = xf_vector(in.inv, ray.dir);
+                        t_hi = rec.t;
+                        cull = in.cull != 0u;
+                        next = reinterpret_cast<const float4*>(&sc.objects[in.object_id]);
+                        slot = 0;
+                        sp = 0;
+                        phase = ST_POP;
+                        break;
+                    }
+                    // every instance has been visited: the rest of trace_ray, trace.rs:97-172
+                    if (seg == 0 && fr.hit_triangle) {
+                        fr.hit_triangle[idx] = rec.triangle_id;
+                        fr.hit_instance[idx] = rec.instance_id;
+                        fr.hit_t_bits[idx] = __float_as_uint(rec.t);
+                    }
+                    if (COUNT) {
+                        if (seg == 0 && fr.box_tests) {
+                            fr.box_tests[idx] = rec.box_tests;
+                            fr.triangle_tests[idx] = rec.triangle_tests;
+                        }
+                        n_box += rec.box_tests;
+                        n_internal += rec.internal_visits;
+                        n_tri += rec.triangle_tests;
+                    }
+                    int state = shade(sc, cam, rec, ray, seed, color);
+                    seg += 1;
+                    if (state == STATE_RAY && seg < cam.depth) {
+                        ctl = CT_START_SEGMENT;
+                        continue;
+                    }
+                    if (state == STATE_RAY) color = v3(0.0f, 0.0f, 0.0f);  // never finished bouncing, trace.rs:204-205
+                    // shader/src/lib.rs:71-98, then the event loop's bookkeeping, main.rs:147-148
+                    float4 next_acc;
+                    accumulate(fwm, acc, color, next_acc, shown);
+                    acc = next_acc;
+                    n_paths += 1;
+                    frame += 1u;
+                    fwm += 1.0f;
+                    frames_left -= 1u;
+                    if (frames_left == 0u) {
+                        reinterpret_cast<float4*>(fr.acc)[idx] = acc;
+                        if (fr.present) reinterpret_cast<float4*>(fr.present)[idx] = gamma_correct(shown);
+                        ctl = CT_NEW_PIXEL;
+                        break;
+                    }
+                    ctl = CT_NEW_PATH;
                 }
-                if (state == STATE_RAY) color = v3(0.0f, 0.0f, 0.0f);
-                float4 next_acc;
-                accumulate(fwm, acc, color, next_acc, shown);
-                acc = next_acc;
-                n_paths += 1;
-                frame += 1u;
-                fwm += 1.0f;
-                frames_left -= 1u;
-                if (frames_left == 0u) {
-                    reinterpret_cast<float4*>(fr.acc)[idx] = acc;
-                    if (fr.present) reinterpret_cast<float4*>(fr.present)[idx] = gamma_correct(shown);
-                    phase = ST_DEAD;
-                    break;
-                }
-                ctl = CT_NEW_PATH;
             }
         } else if ((pick == 2 && phase == ST_LEAF) || (pick == 1 && (phase == ST_DESC || phase == ST_POP))) {
             bool finished = false;  // this lane has to pop (or the instance is done)
@@ -773,48 +398,18 @@ __global__ __launch_bounds__(kBlock) void path_kernel_vote(DevScene sc, DevCam c
             it3 = next[3];
         }
     }
-
-    n_rays = wave_sum(n_rays);
-    n_paths = wave_sum(n_paths);
-    if (COUNT) {
-        n_box = wave_sum(n_box);
-        n_internal = wave_sum(n_internal);
-        n_tri = wave_sum(n_tri);
-    }
-    if (lane == 0 && fr.stats) {
-        atomicAdd(&fr.stats->rays, n_rays);
-        atomicAdd(&fr.stats->paths, n_paths);
-        if (COUNT) {
-            atomicAdd(&fr.stats->box_tests, n_box);
-            atomicAdd(&fr.stats->internal_visits, n_internal);
-            atomicAdd(&fr.stats->triangle_tests, n_tri);
-        }
-    }
+    flush_stats(fr, COUNT, lane, n_rays, n_paths, n_box, n_internal, n_tri);
 }
 
 hipError_t launch_path_kernel(const DevScene& sc, const DevCam& cam, const DevRows& rows, const DevFrame& fr,
-                              uint32_t n_frames, uint32_t stack_needed, bool count, int variant,
-                              hipStream_t stream) {
+                              uint32_t n_frames, uint32_t stack_needed, bool count, hipStream_t stream) {
     const uint32_t tiles_x = (cam.W + kTileW - 1) / kTileW;
     const uint32_t tiles_y = (rows.local_rows + kTileH - 1) / kTileH;
     const uint32_t n_tiles = tiles_x * tiles_y;
     if (n_tiles == 0) return hipSuccess;
     dim3 grid(n_tiles), block(kBlock);
-#define RT_LAUNCH(N, C)                                                                                        \
-    do {                                                                                                       \
-        if (variant == 0)                                                                                      \
-            hipLaunchKernelGGL((path_kernel<N, C>), grid, block, 0, stream, sc, cam, rows, fr, n_frames,       \
-                               tiles_x, n_tiles);                                                              \
-        else if (variant == 1)                                                                                 \
-            hipLaunchKernelGGL((path_kernel_sched<N, C>), grid, block, 0, stream, sc, cam, rows, fr, n_frames, \
-                               tiles_x, n_tiles);                                                              \
-        else if (variant == 2)                                                                                 \
-            hipLaunchKernelGGL((path_kernel_step<N, C>), grid, block, 0, stream, sc, cam, rows, fr, n_frames,  \
-                               tiles_x, n_tiles);                                                              \
-        else                                                                                                   \
-            hipLaunchKernelGGL((path_kernel_vote<N, C, 1, 1, 1>), grid, block, 0, stream, sc, cam, rows, fr,   \
-                               n_frames, tiles_x, n_tiles);                                                    \
-    } while (0)
+#define RT_LAUNCH(N, C) \
+    hipLaunchKernelGGL((path_kernel<N, C>), grid, block, 0, stream, sc, cam, rows, fr, n_frames, tiles_x, n_tiles)
     if (stack_needed <= 32) {
         if (count) RT_LAUNCH(32, true); else RT_LAUNCH(32, false);
     } else if (stack_needed <= 64) {
@@ -824,6 +419,44 @@ hipError_t launch_path_kernel(const DevScene& sc, const DevCam& cam, const DevRo
     }
 #undef RT_LAUNCH
     return hipGetLastError();
+}
+
+hipError_t launch_persistent_kernel(const DevScene& sc, const DevCam& cam, const DevRows& rows, const DevFrame& fr,
+                                    DevQueue q, uint32_t n_frames, uint32_t stack_needed, bool count,
+                                    uint32_t n_blocks, hipStream_t stream) {
+    // 8x8-pixel tiles of this context's rows, split into 8 contiguous ranges
+    q.tiles_x = (cam.W + 7u) / 8u;
+    const uint32_t tiles_y = (rows.local_rows + 7u) / 8u;
+    const uint32_t n_tiles = q.tiles_x * tiles_y;
+    if (n_tiles == 0 || n_blocks == 0) return hipSuccess;
+    for (uint32_t i = 0; i <= 8; ++i) q.first_item[i] = (uint32_t)(((uint64_t)n_tiles * i) / 8u) * 64u;
+    hipError_t e = hipMemsetAsync(q.head, 0, 8 * 32 * sizeof(uint32_t), stream);
+    if (e != hipSuccess) return e;
+    dim3 grid(n_blocks), block(kBlock);
+#define RT_LAUNCH(N, C) \
+    hipLaunchKernelGGL((path_kernel_persistent<N, C>), grid, block, 0, stream, sc, cam, rows, fr, q, n_frames)
+    if (stack_needed <= 32) {
+        if (count) RT_LAUNCH(32, true); else RT_LAUNCH(32, false);
+    } else if (stack_needed <= 64) {
+        if (count) RT_LAUNCH(64, true); else RT_LAUNCH(64, false);
+    } else {
+        return hipErrorInvalidValue;
+    }
+#undef RT_LAUNCH
+    return hipGetLastError();
+}
+
+int persistent_blocks_per_cu(uint32_t stack_needed, bool count) {
+    int n = 0;
+    hipError_t e;
+    if (stack_needed <= 32) {
+        e = count ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, path_kernel_persistent<32, true>, kBlock, 0)
+                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, path_kernel_persistent<32, false>, kBlock, 0);
+    } else {
+        e = count ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, path_kernel_persistent<64, true>, kBlock, 0)
+                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, path_kernel_persistent<64, false>, kBlock, 0);
+    }
+    return e == hipSuccess && n > 0 ? n : 1;
 }
 
 }  // namespace rt

@@ -7,11 +7,20 @@
 
 namespace rt {
 
-// Whole-path kernel.  `stack_needed` = entries of per-lane traversal stack the
-// scene's deepest BVH can use; `count` keeps the reference's debug counters;
-// `variant` 0 = plain nested loops, 1 = per-lane state machine (same results).
+// Plain whole-path kernel (one lane per pixel, nested loops).  `stack_needed` =
+// entries of per-lane traversal stack the scene's deepest BVH can use; `count`
+// keeps the reference's debug counters.
 hipError_t launch_path_kernel(const DevScene& sc, const DevCam& cam, const DevRows& rows, const DevFrame& fr,
-                              uint32_t n_frames, uint32_t stack_needed, bool count, int variant,
-                              hipStream_t stream);
+                              uint32_t n_frames, uint32_t stack_needed, bool count, hipStream_t stream);
+
+// Persistent whole-path kernel (per-lane state machine, vote-scheduled, work
+// queues).  `q.head` must point at 8 * 32 words of device memory; `n_blocks`
+// is the number of resident workgroups to launch.
+hipError_t launch_persistent_kernel(const DevScene& sc, const DevCam& cam, const DevRows& rows, const DevFrame& fr,
+                                    DevQueue q, uint32_t n_frames, uint32_t stack_needed, bool count,
+                                    uint32_t n_blocks, hipStream_t stream);
+
+// Workgroups of the persistent kernel one CU can hold (occupancy query).
+int persistent_blocks_per_cu(uint32_t stack_needed, bool count);
 
 }  // namespace rt

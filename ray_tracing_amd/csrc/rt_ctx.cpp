@@ -4,6 +4,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -40,9 +41,12 @@ struct rt_ctx {
     uint32_t* d_box = nullptr;
     uint32_t* d_tritests = nullptr;
     DevStats* d_stats = nullptr;
+    uint32_t* d_queue = nullptr;  // work-queue heads of the persistent kernel
+    int n_cus = 0;
+    int vote_w[3] = {1, 1, 1};
 
     // options
-    int pipeline = 3;
+    int pipeline = 1;
     bool probe_hits = false;
     bool counters = false;
     bool present = true;
@@ -189,7 +193,18 @@ int render(rt_ctx* c, const rt_cam_data& cam, uint32_t n_frames) {
     const uint32_t stack_needed = c->max_depth > 1 ? c->max_depth - 1 : 1;
 
     RT_HIP(c, hipEventRecord(c->ev0, c->stream));
-    RT_HIP(c, launch_path_kernel(sc, dc, rows, fr, n_frames, stack_needed, count, c->pipeline, c->stream));
+    if (c->pipeline == 0) {
+        RT_HIP(c, launch_path_kernel(sc, dc, rows, fr, n_frames, stack_needed, count, c->stream));
+    } else {
+        DevQueue q;
+        std::memset(&q, 0, sizeof q);
+        q.head = c->d_queue;
+        q.w_ctl = c->vote_w[0];
+        q.w_box = c->vote_w[1];
+        q.w_leaf = c->vote_w[2];
+        const uint32_t n_blocks = (uint32_t)(c->n_cus * persistent_blocks_per_cu(stack_needed, count));
+        RT_HIP(c, launch_persistent_kernel(sc, dc, rows, fr, q, n_frames, stack_needed, count, n_blocks, c->stream));
+    }
     RT_HIP(c, hipEventRecord(c->ev1, c->stream));
     c->timed = true;
     return RT_OK;
@@ -221,6 +236,18 @@ int rt_create(int device, rt_ctx** out) {
     if ((e = hipEventCreate(&c->ev1)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipMalloc(&c->d_stats, sizeof(DevStats))) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMemset(c->d_stats, 0, sizeof(DevStats))) != hipSuccess) return bail("hipMemset", e);
+    if ((e = hipMalloc(&c->d_queue, 8 * 32 * sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc", e);
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return bail("hipGetDeviceProperties", e);
+    c->n_cus = prop.multiProcessorCount;
+    if (const char* w = std::getenv("RT_VOTE_WEIGHTS")) {
+        int a = 1, b = 1, d = 1;
+        if (std::sscanf(w, "%d,%d,%d", &a, &b, &d) == 3 && a > 0 && b > 0 && d > 0) {
+            c->vote_w[0] = a;
+            c->vote_w[1] = b;
+            c->vote_w[2] = d;
+        }
+    }
     *out = c;
     return RT_OK;
 }
@@ -232,6 +259,7 @@ void rt_destroy(rt_ctx* c) {
     free_scene(c);
     free_frame(c);
     free_dev(c->d_stats);
+    free_dev(c->d_queue);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     delete c;
@@ -249,7 +277,7 @@ int rt_set_option(rt_ctx* c, int option, int64_t value) {
     if (!c) return RT_ERR_INVALID;
     switch (option) {
         case RT_OPT_PIPELINE:
-            if (value < 0 || value > 3) return fail(c, RT_ERR_INVALID, "unknown pipeline");
+            if (value < 0 || value > 1) return fail(c, RT_ERR_INVALID, "unknown pipeline");
             c->pipeline = (int)value;
             return RT_OK;
         case RT_OPT_PROBE_HITS: c->probe_hits = value != 0; return RT_OK;
