@@ -73,6 +73,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--grid", type=int, default=700, help="terrain grid resolution (700 -> ~1.0 M triangles)")
+    ap.add_argument("--leaf-max", type=int, default=16, help="largest leaf the BVH builder leaves unsplit (bvh.rs: 16)")
     ap.add_argument("--pipeline", type=int, default=1, help="kernel: 0 plain nested loops, 1 persistent state machine")
     args = ap.parse_args()
 
@@ -94,7 +95,8 @@ def main():
     from ray_tracing_amd import _lib as L
 
     threads = min(os.cpu_count() or 1, 16)
-    scene, cam0 = terrain_scene(WIDTH, HEIGHT, n=args.grid, depth=DEPTH, threads=max(1, threads // max(1, world)))
+    scene, cam0 = terrain_scene(WIDTH, HEIGHT, n=args.grid, depth=DEPTH, threads=max(1, threads // max(1, world)),
+                                leaf_max=args.leaf_max)
     n_inst = int(scene.info.num_instances)
 
     def fresh_cam():
@@ -121,6 +123,7 @@ def main():
     one_step()
     app.synchronize()
     counted = app.stats()
+    sched = app.sched_stats()
     app.set_option(RT_OPT_COUNTERS, 0)
 
     for _ in range(args.warmup):
@@ -174,7 +177,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "path_kernel", "kernel_ms": last_ms,
                          "algorithmic_bytes_per_launch": rank_bytes,
-                         "counters_per_launch": counted},
+                         "counters_per_launch": counted, "schedule_per_launch": sched},
         }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"], _ = cpu_baseline(scene, fresh_cam())

@@ -109,6 +109,15 @@ int rt_write_acc(rt_ctx* ctx, const float* rgba, size_t n_pixels, uint32_t width
 int rt_read_hits(rt_ctx* ctx, uint32_t* triangle_id, uint32_t* instance_id, uint32_t* t_bits, size_t n_pixels);
 int rt_read_counters(rt_ctx* ctx, uint32_t* box_tests, uint32_t* triangle_tests, size_t n_pixels);
 int rt_get_stats(rt_ctx* ctx, rt_stats* out);
+/* Scheduling profile of the persistent kernel since the last rt_reset_stats
+ * (maintained while RT_OPT_COUNTERS is on): per kind of step (0 control,
+ * 1 box, 2 triangle) the wave iterations that ran it and the lanes that took
+ * part.  lanes / (64 * iterations) is the lane utilisation of that kind. */
+typedef struct rt_sched_stats {
+    uint64_t iterations[3];
+    uint64_t lanes[3];
+} rt_sched_stats;
+int rt_get_sched_stats(rt_ctx* ctx, rt_sched_stats* out);
 int rt_reset_stats(rt_ctx* ctx);
 /* Device address of the accumulation buffer (canvas W*H*4 f32) of the current
  * canvas size, for callers that reduce it across GPUs themselves. */

@@ -67,6 +67,10 @@ class Stats(C.Structure):
                 ("triangle_tests", C.c_uint64), ("paths", C.c_uint64)]
 
 
+class SchedStats(C.Structure):
+    _fields_ = [("iterations", C.c_uint64 * 3), ("lanes", C.c_uint64 * 3)]
+
+
 class BvhParams(C.Structure):
     _fields_ = [("root_leaf_max", C.c_uint32), ("leaf_max", C.c_uint32), ("max_depth", C.c_uint32),
                 ("threads", C.c_int32)]
@@ -109,6 +113,7 @@ SIGNATURES = {
     "rt_read_hits": (_i32, [_vp, _vp, _vp, _vp, _sz]),
     "rt_read_counters": (_i32, [_vp, _vp, _vp, _sz]),
     "rt_get_stats": (_i32, [_vp, _P(Stats)]),
+    "rt_get_sched_stats": (_i32, [_vp, _P(SchedStats)]),
     "rt_reset_stats": (_i32, [_vp]),
     "rt_acc_device_ptr": (_i32, [_vp, _u32, _u32, _P(_vp)]),
     "rt_last_render_ms": (_i32, [_vp, _P(_f)]),

@@ -140,6 +140,11 @@ class App:
         self._check(self._lib.rt_get_stats(self._ctx, C.byref(s)))
         return {k: int(getattr(s, k)) for k, _ in L.Stats._fields_}
 
+    def sched_stats(self):
+        s = L.SchedStats()
+        self._check(self._lib.rt_get_sched_stats(self._ctx, C.byref(s)))
+        return {"iterations": list(s.iterations), "lanes": list(s.lanes)}
+
     def reset_stats(self):
         self._check(self._lib.rt_reset_stats(self._ctx))
 

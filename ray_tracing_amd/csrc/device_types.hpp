@@ -49,18 +49,22 @@ struct alignas(64) DevObject {
     DevChild unused;  // pads the record to the 64 bytes of a DevNode
 };
 
-struct alignas(16) DevInstance {
-    float inv[12];   // inverse transform: X, Y, Z, T  (object <- world)
-    float fwd[12];   // transform:         X, Y, Z, T  (world <- object)
+// The first 64 bytes have the shape of a DevNode whose child 0 is the root of
+// the instance's object, so "start traversing this instance" is an ordinary
+// item fetch (slot 0).
+struct alignas(64) DevInstance {
+    DevChild root;   // copy of the object's root record
     uint32_t object_id;
     uint32_t mat_kind;
     uint32_t cull;
     float specular;
     float color[3];
     float specular_roughness;
+    float inv[12];   // inverse transform: X, Y, Z, T  (object <- world)
+    float fwd[12];   // transform:         X, Y, Z, T  (world <- object)
     float roughness;
     float ior;
-    uint32_t pad[2];
+    uint32_t pad[6];
 };
 
 struct DevCam {
@@ -92,6 +96,10 @@ struct DevScene {
 
 struct DevStats {
     unsigned long long rays, box_tests, internal_visits, triangle_tests, paths;
+    // scheduling profile of the persistent kernel (only with counters on):
+    // wave iterations that ran a control / box / triangle step, and the lanes
+    // that took part in them
+    unsigned long long iters[3], lanes[3];
 };
 
 // Work queues of the persistent kernel: 8 ranges of 64-pixel items (8x8 tiles),

@@ -162,6 +162,7 @@ bool build_gpu_scene(const rt_scene_info& info, const rt_vertex* vertices, size_
         pack_affine(inv, di.inv);
         pack_affine(instances[i].transform, di.fwd);
         di.object_id = instances[i].object_id;
+        di.root = out.objects[di.object_id].root;
         rt_material m;
         default_material(uint32_t(i), m);
         apply_material(di, m);

@@ -180,6 +180,7 @@ __global__ __launch_bounds__(kBlock) void path_kernel_persistent(DevScene sc, De
     const unsigned long long lanes_below = (1ull << lane) - 1ull;
 
     unsigned long long n_rays = 0, n_box = 0, n_internal = 0, n_tri = 0, n_paths = 0;
+    unsigned long long sched_iters[3] = {0, 0, 0}, sched_lanes[3] = {0, 0, 0};  // wave-uniform
 
     uint32_t phase = n_frames > 0 ? ST_CONTROL : ST_DEAD;
     uint32_t ctl = CT_NEW_PIXEL;
@@ -215,6 +216,10 @@ __global__ __launch_bounds__(kBlock) void path_kernel_persistent(DevScene sc, De
         const int w_box = __popcll(__ballot(phase == ST_DESC || phase == ST_POP)) * q.w_box;
         const int w_leaf = __popcll(__ballot(phase == ST_LEAF)) * q.w_leaf;
         const int pick = (w_box >= w_leaf && w_box >= w_ctl) ? 1 : (w_leaf >= w_ctl ? 2 : 0);
+        if (COUNT) {
+            sched_iters[pick] += 1;
+            sched_lanes[pick] += (unsigned)((pick == 0 ? w_ctl / q.w_ctl : pick == 1 ? w_box / q.w_box : w_leaf / q.w_leaf));
+        }
 
         if (pick == 0) {
             // one queue per XCD group; every lane that needs a pixel takes part in one fetch
@@ -278,7 +283,7 @@ __global__ __launch_bounds__(kBlock) void path_kernel_persistent(DevScene sc, De
                         ldir = xf_vector(in.inv, ray.dir);
                         t_hi = rec.t;
                         cull = in.cull != 0u;
-                        next = reinterpret_cast<const float4*>(&sc.objects[in.object_id]);
+                        next = reinterpret_cast<const float4*>(&in);
                         slot = 0;
                         sp = 0;
                         phase = ST_POP;
@@ -380,8 +385,20 @@ __global__ __launch_bounds__(kBlock) void path_kernel_persistent(DevScene sc, De
             if (finished) {
                 if (sp == 0) {
                     inst += 1;  // this instance is done, trace.rs:76
-                    ctl = CT_NEXT_INSTANCE;
-                    phase = ST_CONTROL;
+                    if (inst < sc.n_instances) {
+                        // set up the next one at once: it needs no other lane's company
+                        const DevInstance& in = sc.instances[inst];
+                        lpos = xf_point(in.inv, ray.pos);
+                        ldir = xf_vector(in.inv, ray.dir);
+                        t_hi = rec.t;
+                        cull = in.cull != 0u;
+                        next = reinterpret_cast<const float4*>(&in);
+                        slot = 0;
+                        phase = ST_POP;
+                    } else {
+                        ctl = CT_NEXT_INSTANCE;  // shade
+                        phase = ST_CONTROL;
+                    }
                 } else {
                     sp -= 1;
                     uint32_t ref = stack[sp * kBlock];
@@ -399,6 +416,12 @@ __global__ __launch_bounds__(kBlock) void path_kernel_persistent(DevScene sc, De
         }
     }
     flush_stats(fr, COUNT, lane, n_rays, n_paths, n_box, n_internal, n_tri);
+    if (COUNT && lane == 0 && fr.stats) {
+        for (int k = 0; k < 3; ++k) {
+            atomicAdd(&fr.stats->iters[k], sched_iters[k]);
+            atomicAdd(&fr.stats->lanes[k], sched_lanes[k]);
+        }
+    }
 }
 
 hipError_t launch_path_kernel(const DevScene& sc, const DevCam& cam, const DevRows& rows, const DevFrame& fr,

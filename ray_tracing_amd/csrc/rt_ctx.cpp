@@ -438,6 +438,19 @@ int rt_get_stats(rt_ctx* c, rt_stats* out) {
     return RT_OK;
 }
 
+int rt_get_sched_stats(rt_ctx* c, rt_sched_stats* out) {
+    if (!c || !out) return RT_ERR_INVALID;
+    DevStats s;
+    RT_HIP(c, hipSetDevice(c->device));
+    RT_HIP(c, hipMemcpyAsync(&s, c->d_stats, sizeof s, hipMemcpyDeviceToHost, c->stream));
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    for (int k = 0; k < 3; ++k) {
+        out->iterations[k] = s.iters[k];
+        out->lanes[k] = s.lanes[k];
+    }
+    return RT_OK;
+}
+
 int rt_reset_stats(rt_ctx* c) {
     if (!c) return RT_ERR_INVALID;
     RT_HIP(c, hipSetDevice(c->device));

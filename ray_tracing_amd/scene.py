@@ -349,13 +349,14 @@ def sphere_field_scene(width=1920, height=1080, n_spheres=10000, seed=1, subdivi
     return scene, cam
 
 
-def terrain_scene(width=1920, height=1080, n=700, seed=2, depth=10, closed_box=False, threads=8, light=True):
+def terrain_scene(width=1920, height=1080, n=700, seed=2, depth=10, closed_box=False, threads=8, light=True,
+                  leaf_max=16):
     """~1M-triangle procedural terrain as instance 1 (diffuse), a glass cube as
     instance 0 and, with `light`, an emissive sphere as instance 2."""
     cv, cf, ct = _small_glass_cube(6.0, (10.0, 22.0, 5.0))
     tv, tf = terrain(n=n, seed=seed, closed_box=closed_box)
     ident = affine_from_srt((1, 1, 1), (0, 0, 0, 1), (0, 0, 0))
-    b = SceneBuilder().add_mesh(cv, cf, [ct]).add_mesh(tv, tf, [ident], bvh_params(threads=threads))
+    b = SceneBuilder().add_mesh(cv, cf, [ct]).add_mesh(tv, tf, [ident], bvh_params(leaf_max=leaf_max, threads=threads))
     if light:
         lv, lf = icosphere(2)
         b.add_mesh(lv.astype(np.float32), lf, [affine_from_srt((12.0,) * 3, (0, 0, 0, 1), (-30.0, 45.0, 20.0))])
