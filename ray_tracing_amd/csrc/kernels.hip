@@ -150,9 +150,9 @@ __global__ __launch_bounds__(kBlock) void path_kernel(DevScene sc, DevCam cam, D
 // Same per-lane work, in the same per-lane order, as path_kernel -- so the
 // results are identical -- but scheduled for 64-wide waves:
 //
-//  * Each lane is a small state machine that owns ONE pending 64-byte item (an
-//    internal node, the parent node of a popped child, an object's root record
-//    or a triangle).  The load of the item is issued at the end of one step and
+//  * Each lane is a small state machine that owns ONE pending item (a 64-byte
+//    internal node, a 64-byte triangle, or the 32-byte record of a popped child
+//    or of an object's root).  The load of the item is issued at the end of one step and
 //    consumed by the next, so a lane never has two dependent fetches in a step.
 //  * A step is one of three kinds: CONTROL (generate a path, start a segment,
 //    set up the next instance, or shade + accumulate after the last instance),
@@ -206,7 +206,6 @@ __global__ __launch_bounds__(kBlock) void path_kernel_persistent(DevScene sc, De
     bool cull = false;
     float4 it0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), it1 = it0, it2 = it0, it3 = it0;  // the pending item
     uint32_t node = 0;  // ST_DESC: index of the node held in the item
-    uint32_t slot = 0;  // ST_POP: which child of the item is meant
     uint32_t tri_i = 0, tri_last = 0, sp = 0;
 
     while (phase != ST_DEAD) {
@@ -284,7 +283,6 @@ __global__ __launch_bounds__(kBlock) void path_kernel_persistent(DevScene sc, De
                         t_hi = rec.t;
                         cull = in.cull != 0u;
                         next = reinterpret_cast<const float4*>(&in);
-                        slot = 0;
                         sp = 0;
                         phase = ST_POP;
                         break;
@@ -360,8 +358,8 @@ __global__ __launch_bounds__(kBlock) void path_kernel_persistent(DevScene sc, De
                     lo = first_is_1 ? it0 : it2;
                     hi = first_is_1 ? it1 : it3;
                 } else {
-                    lo = slot ? it2 : it0;
-                    hi = slot ? it3 : it1;
+                    lo = it0;  // the item is the child record itself
+                    hi = it1;
                 }
                 // the node on top of the reference's stack: hit.rs:77-86
                 if (COUNT) rec.box_tests += 1;
@@ -393,7 +391,6 @@ __global__ __launch_bounds__(kBlock) void path_kernel_persistent(DevScene sc, De
                         t_hi = rec.t;
                         cull = in.cull != 0u;
                         next = reinterpret_cast<const float4*>(&in);
-                        slot = 0;
                         phase = ST_POP;
                     } else {
                         ctl = CT_NEXT_INSTANCE;  // shade
@@ -402,17 +399,18 @@ __global__ __launch_bounds__(kBlock) void path_kernel_persistent(DevScene sc, De
                 } else {
                     sp -= 1;
                     uint32_t ref = stack[sp * kBlock];
-                    slot = ref & 1u;
                     phase = ST_POP;
-                    next = reinterpret_cast<const float4*>(&sc.nodes[ref >> 1]);
+                    next = reinterpret_cast<const float4*>(&sc.nodes[ref >> 1].c[ref & 1u]);
                 }
             }
         }
         if (next) {
             it0 = next[0];
             it1 = next[1];
-            it2 = next[2];
-            it3 = next[3];
+            if (phase != ST_POP) {  // a child record is 32 bytes, a node or a triangle 64
+                it2 = next[2];
+                it3 = next[3];
+            }
         }
     }
     flush_stats(fr, COUNT, lane, n_rays, n_paths, n_box, n_internal, n_tri);

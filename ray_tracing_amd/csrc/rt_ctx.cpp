@@ -43,7 +43,7 @@ struct rt_ctx {
     DevStats* d_stats = nullptr;
     uint32_t* d_queue = nullptr;  // work-queue heads of the persistent kernel
     int n_cus = 0;
-    int vote_w[3] = {1, 1, 1};
+    int vote_w[3] = {2, 1, 3};  // vote weights: control, box, triangle steps
 
     // options
     int pipeline = 1;
