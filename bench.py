@@ -115,6 +115,7 @@ def main():
     def one_step():
         # a step = the whole 16-sample job from a zeroed accumulator
         app.cam_data = fresh_cam()
+        app.clear_acc()
         app.render_frames(FRAMES_PER_STEP)
 
     # --- counter pass (untimed): the reference's debug counters for one step --------------

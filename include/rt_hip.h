@@ -46,10 +46,12 @@ typedef struct rt_stats {
 } rt_stats;
 
 enum {
-    /* 0 = one lane per pixel walks its whole path in one kernel (the shape of
-     *     the reference's shader::main); 1 = wavefront pipeline
-     *     generate / extend / shade / accumulate over a path-state SoA with
-     *     wave64 compaction between bounces. */
+    /* Which kernel renders.  Both compute the same bits.
+     * 0 = plain: one lane per pixel runs nested frame / segment / instance /
+     *     traversal loops, the shape of the reference's shader::main;
+     * 1 = persistent (default): per-lane state machine (generate, extend,
+     *     shade, accumulate as steps), wave-wide vote on the kind of step to
+     *     run, lanes refilled from per-XCD work queues. */
     RT_OPT_PIPELINE = 1,
     /* 1 = also record, for the FIRST segment of every path, the HitRecord
      *     (triangle_id, instance_id, t bits) -> rt_read_hits. */
@@ -58,7 +60,17 @@ enum {
      *     per-pixel values -> rt_read_counters, sums -> rt_get_stats. */
     RT_OPT_COUNTERS = 3,
     /* 0 = skip the gamma pass (binding 8 is then never written). default 1 */
-    RT_OPT_PRESENT = 4
+    RT_OPT_PRESENT = 4,
+    /* How far CamData.frame advances after each frame of rt_render_frames
+     * (default 1, main.rs:147).  With G GPUs splitting the samples of a pixel,
+     * GPU g starts at frame g and uses stride G. */
+    RT_OPT_FRAME_STRIDE = 5,
+    /* 0 (default) = a frame's seed hashes the pixel's previous accumulator value
+     *     (lib.rs:57-60), which chains the samples of a pixel;
+     * 1 = it hashes zeros instead: get_seed(frame, x, y, 0, 0, 0).  Samples become
+     *     independent of each other, which sample-splitting across GPUs needs.
+     *     Not the reference's sequence: comparable to it only statistically. */
+    RT_OPT_SEED_MODE = 6
 };
 
 /* ---- lifecycle: vulkan::App::create / App::destroy (vulkan.rs:124-168, 374) ---- */
@@ -104,6 +116,8 @@ int rt_synchronize(rt_ctx* ctx);
 int rt_read_acc(rt_ctx* ctx, float* rgba, size_t n_pixels);     /* binding 7 */
 int rt_read_present(rt_ctx* ctx, float* rgba, size_t n_pixels); /* binding 8 */
 int rt_write_acc(rt_ctx* ctx, const float* rgba, size_t n_pixels, uint32_t width, uint32_t height);
+/* Zero binding 7 on the device, as it is right after buffer creation. */
+int rt_clear_acc(rt_ctx* ctx);
 /* parity probes, no counterpart in the reference's API (its HitRecord and
  * debug counters never leave the shader): first-segment values per pixel */
 int rt_read_hits(rt_ctx* ctx, uint32_t* triangle_id, uint32_t* instance_id, uint32_t* t_bits, size_t n_pixels);

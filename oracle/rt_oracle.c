@@ -637,7 +637,9 @@ static void shade_pixel(const orc_scene* s, const rt_cam_data* cam, uint32_t x, 
     uint32_t idx = x + y * cam->canvas_width;
     float* a = &acc[(size_t)idx * 4];
     float prev[4] = {a[0], a[1], a[2], a[3]};
-    uint32_t seed = orc_get_seed(cam->frame, x, y, prev[0], prev[1], prev[2]);
+    uint32_t seed = (trig_mode & ORC_SEED_INDEPENDENT) ? orc_get_seed(cam->frame, x, y, 0.0f, 0.0f, 0.0f)
+                                                       : orc_get_seed(cam->frame, x, y, prev[0], prev[1], prev[2]);
+    trig_mode &= 0xFF;
 
     path_probe pp;
     memset(&pp, 0, sizeof pp);

@@ -29,7 +29,11 @@ extern "C" {
 /* How sin/cos in rand_vec_in_unit_sphere (material.rs:30-31) are evaluated. */
 enum {
     ORC_TRIG_LIBM = 0, /* host libm sinf/cosf: what host Rust would call        */
-    ORC_TRIG_DET  = 1  /* fixed polynomial, op order shared with the HIP kernel */
+    ORC_TRIG_DET  = 1, /* fixed polynomial, op order shared with the HIP kernel */
+    /* OR-ed into the mode word of orc_render_frame: the per-frame seed hashes zeros
+     * instead of the previous accumulator (a documented variant used when the samples
+     * of a pixel are split over several GPUs; not the reference's sequence) */
+    ORC_SEED_INDEPENDENT = 0x100
 };
 
 typedef struct orc_scene {

@@ -86,6 +86,7 @@ for _t, _n in _SIZES.items():
 RT_OK = 0
 RT_ERR_INVALID, RT_ERR_HIP, RT_ERR_NO_SCENE, RT_ERR_LIMIT = -1, -2, -3, -4
 RT_OPT_PIPELINE, RT_OPT_PROBE_HITS, RT_OPT_COUNTERS, RT_OPT_PRESENT = 1, 2, 3, 4
+RT_OPT_FRAME_STRIDE, RT_OPT_SEED_MODE = 5, 6
 RT_MAT_GENERIC, RT_MAT_NORMAL, RT_MAT_EMISSIVE = 0, 1, 2
 RT_DEBUG_NONE, RT_DEBUG_TRIANGLE_INTERSECTION, RT_DEBUG_BVH_INTERSECTION = 0, 1, 2
 
@@ -110,6 +111,7 @@ SIGNATURES = {
     "rt_read_acc": (_i32, [_vp, _vp, _sz]),
     "rt_read_present": (_i32, [_vp, _vp, _sz]),
     "rt_write_acc": (_i32, [_vp, _vp, _sz, _u32, _u32]),
+    "rt_clear_acc": (_i32, [_vp]),
     "rt_read_hits": (_i32, [_vp, _vp, _vp, _vp, _sz]),
     "rt_read_counters": (_i32, [_vp, _vp, _vp, _sz]),
     "rt_get_stats": (_i32, [_vp, _P(Stats)]),

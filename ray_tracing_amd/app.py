@@ -125,6 +125,9 @@ class App:
         h, w = self._shape()
         self._check(self._lib.rt_write_acc(self._ctx, _ptr(rgba), w * h, w, h))
 
+    def clear_acc(self):
+        self._check(self._lib.rt_clear_acc(self._ctx))
+
     def read_hits(self):
         tri, inst, tb = (np.empty(self._shape(), np.uint32) for _ in range(3))
         self._check(self._lib.rt_read_hits(self._ctx, _ptr(tri), _ptr(inst), _ptr(tb), self._n()))
@@ -153,6 +156,18 @@ class App:
         h, w = self._shape()
         self._check(self._lib.rt_acc_device_ptr(self._ctx, w, h, C.byref(p)))
         return p.value
+
+    def acc_tensor(self):
+        """The accumulation buffer as a torch tensor (H, W, 4) aliasing device memory."""
+        import torch
+
+        h, w = self._shape()
+
+        class _Alias:
+            __cuda_array_interface__ = {"shape": (h, w, 4), "typestr": "<f4", "data": (self.acc_device_ptr(), False),
+                                        "version": 2, "strides": None}
+
+        return torch.as_tensor(_Alias(), device=torch.device("cuda", torch.cuda.current_device()))
 
     def last_render_ms(self):
         ms = C.c_float()

@@ -77,6 +77,8 @@ struct DevCam {
     uint32_t debug_number;
     uint32_t debug_information;
     float frames_without_move;
+    uint32_t frame_stride;  // how far `frame` moves between consecutive frames of one call
+    uint32_t seed_mode;     // 0: the seed hashes the previous accumulator (lib.rs:57-60); 1: it hashes zeros
 };
 
 // Which rows of the canvas this context renders: strips of `strip_h` rows are

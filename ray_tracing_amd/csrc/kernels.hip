@@ -95,7 +95,8 @@ __global__ __launch_bounds__(kBlock) void path_kernel(DevScene sc, DevCam cam, D
 
         for (uint32_t f = 0; f < n_frames; ++f) {
             // shader/src/lib.rs:57-69
-            uint32_t seed = get_seed(cam.frame, x, y, acc.x, acc.y, acc.z);
+            uint32_t seed = cam.seed_mode ? get_seed(cam.frame, x, y, 0.0f, 0.0f, 0.0f)
+                                          : get_seed(cam.frame, x, y, acc.x, acc.y, acc.z);
             // Ray::get_color, trace.rs:175-206
             V3 color = v3(1.0f, 1.0f, 1.0f);
             float jx = rand_float(seed, 0.0f, 1.0f);
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(kBlock) void path_kernel(DevScene sc, DevCam cam, D
             accumulate(cam.frames_without_move, acc, color, next_acc, shown);
             acc = next_acc;
             // the event loop's bookkeeping between frames, main.rs:147-148
-            cam.frame += 1u;
+            cam.frame += cam.frame_stride;
             cam.frames_without_move += 1.0f;
         }
 
@@ -258,7 +259,8 @@ __global__ __launch_bounds__(kBlock) void path_kernel_persistent(DevScene sc, De
                 for (;;) {
                     if (ctl == CT_NEW_PATH) {
                         // shader/src/lib.rs:57-69 and Ray::get_color, trace.rs:175-191
-                        seed = get_seed(frame, x, y, acc.x, acc.y, acc.z);
+                        seed = cam.seed_mode ? get_seed(frame, x, y, 0.0f, 0.0f, 0.0f)
+                                             : get_seed(frame, x, y, acc.x, acc.y, acc.z);
                         color = v3(1.0f, 1.0f, 1.0f);
                         float jx = rand_float(seed, 0.0f, 1.0f);
                         float jy = rand_float(seed, 0.0f, 1.0f);
@@ -314,7 +316,7 @@ __global__ __launch_bounds__(kBlock) void path_kernel_persistent(DevScene sc, De
                     accumulate(fwm, acc, color, next_acc, shown);
                     acc = next_acc;
                     n_paths += 1;
-                    frame += 1u;
+                    frame += cam.frame_stride;
                     fwm += 1.0f;
                     frames_left -= 1u;
                     if (frames_left == 0u) {

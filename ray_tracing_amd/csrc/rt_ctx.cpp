@@ -50,6 +50,8 @@ struct rt_ctx {
     bool probe_hits = false;
     bool counters = false;
     bool present = true;
+    uint32_t frame_stride = 1;
+    uint32_t seed_mode = 0;
     uint32_t strip_h = 0, rank = 0, world = 1;
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -141,7 +143,7 @@ uint32_t local_rows(uint32_t H, uint32_t strip_h, uint32_t rank, uint32_t world)
     return rows;
 }
 
-DevCam make_cam(const rt_cam_data& cam) {
+DevCam make_cam(const rt_cam_data& cam, uint32_t frame_stride, uint32_t seed_mode) {
     DevCam d;
     std::memcpy(d.X, cam.transform.x_axis, 12);
     std::memcpy(d.Y, cam.transform.y_axis, 12);
@@ -161,6 +163,8 @@ DevCam make_cam(const rt_cam_data& cam) {
     d.debug_number = cam.debug_number;
     d.debug_information = cam.debug_information;
     d.frames_without_move = cam.frames_without_move;
+    d.frame_stride = frame_stride;
+    d.seed_mode = seed_mode;
     return d;
 }
 
@@ -172,7 +176,7 @@ int render(rt_ctx* c, const rt_cam_data& cam, uint32_t n_frames) {
     if (n_frames == 0) return RT_OK;
 
     DevScene sc{c->d_nodes, c->d_tris, c->d_objects, c->d_instances, c->n_instances};
-    DevCam dc = make_cam(cam);
+    DevCam dc = make_cam(cam, c->frame_stride, c->seed_mode);
     DevRows rows;
     rows.strip_h = c->world > 1 ? c->strip_h : cam.canvas_height;
     rows.rank = c->rank;
@@ -283,6 +287,14 @@ int rt_set_option(rt_ctx* c, int option, int64_t value) {
         case RT_OPT_PROBE_HITS: c->probe_hits = value != 0; return RT_OK;
         case RT_OPT_COUNTERS: c->counters = value != 0; return RT_OK;
         case RT_OPT_PRESENT: c->present = value != 0; return RT_OK;
+        case RT_OPT_FRAME_STRIDE:
+            if (value < 1 || value > 0x7FFFFFFF) return fail(c, RT_ERR_INVALID, "frame stride must be >= 1");
+            c->frame_stride = (uint32_t)value;
+            return RT_OK;
+        case RT_OPT_SEED_MODE:
+            if (value < 0 || value > 1) return fail(c, RT_ERR_INVALID, "unknown seed mode");
+            c->seed_mode = (uint32_t)value;
+            return RT_OK;
         default: return fail(c, RT_ERR_INVALID, "unknown option");
     }
 }
@@ -371,7 +383,7 @@ int rt_render_frames(rt_ctx* c, rt_cam_data* cam, uint32_t n) {
     int rc = render(c, *cam, n);
     if (rc != RT_OK) return rc;
     for (uint32_t i = 0; i < n; ++i) {  // main.rs:147-148
-        cam->frame += 1;
+        cam->frame += c->frame_stride;
         cam->frames_without_move += 1.0f;
     }
     return RT_OK;
@@ -407,6 +419,14 @@ int rt_write_acc(rt_ctx* c, const float* rgba, size_t n, uint32_t width, uint32_
     if (rc != RT_OK) return rc;
     RT_HIP(c, hipMemcpyAsync(c->d_acc, rgba, n * 16, hipMemcpyHostToDevice, c->stream));
     RT_HIP(c, hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+int rt_clear_acc(rt_ctx* c) {
+    if (!c) return RT_ERR_INVALID;
+    if (!c->d_acc) return RT_OK;  // nothing rendered yet: the buffer will start zeroed
+    RT_HIP(c, hipSetDevice(c->device));
+    RT_HIP(c, hipMemsetAsync(c->d_acc, 0, (size_t)c->W * c->H * 16, c->stream));
     return RT_OK;
 }
 

@@ -14,6 +14,7 @@ ORACLE_DIR = os.path.join(ROOT, "oracle")
 ORACLE_SO = os.path.join(ORACLE_DIR, "_build", "librt_oracle.so")
 
 TRIG_LIBM, TRIG_DET = 0, 1
+SEED_INDEPENDENT = 0x100
 
 
 class OrcScene(C.Structure):
@@ -118,11 +119,13 @@ def orc_scene(scene: Scene, materials=None):
 class OracleRenderer:
     """Frame-by-frame CPU rendering with the accumulate rule of shader/src/lib.rs."""
 
-    def __init__(self, scene: Scene, cam: L.CamData, trig=TRIG_DET, threads=8, materials=None):
+    def __init__(self, scene: Scene, cam: L.CamData, trig=TRIG_DET, threads=8, materials=None, frame_stride=1,
+                 independent_seeds=False):
         self.lib = load()
         self.scene = orc_scene(scene, materials)
         self.cam = L.CamData.from_buffer_copy(cam)
-        self.trig, self.threads = trig, threads
+        self.trig, self.threads = trig | (SEED_INDEPENDENT if independent_seeds else 0), threads
+        self.frame_stride = frame_stride
         h, w = int(cam.canvas_height), int(cam.canvas_width)
         self.acc = np.zeros((h, w, 4), np.float32)
         self.present = np.zeros((h, w, 4), np.float32)
@@ -134,16 +137,28 @@ class OracleRenderer:
         self.stats = OrcStats()
 
     def render(self, n_frames=1, rows=None):
+        """`rows`: None for the whole canvas, else an array of canvas rows to render
+        (the others keep whatever the buffers hold)."""
         h = int(self.cam.canvas_height)
-        y0, y1 = rows if rows else (0, h)
+        if rows is None:
+            spans = [(0, h)]
+        else:
+            rows = sorted(int(y) for y in rows)
+            spans, start = [], 0
+            for k in range(1, len(rows) + 1):
+                if k == len(rows) or rows[k] != rows[k - 1] + 1:
+                    spans.append((rows[start], rows[k - 1] + 1))
+                    start = k
         probe = OrcProbe(_ptr(self.hit_triangle), _ptr(self.hit_instance), _ptr(self.hit_t_bits),
                          _ptr(self.box_tests), _ptr(self.triangle_tests))
         for _ in range(n_frames):
-            rc = self.lib.orc_render_frame(C.byref(self.scene), C.byref(self.cam), _ptr(self.acc), _ptr(self.present),
-                                           C.byref(probe), C.byref(self.stats), y0, y1, self.threads, self.trig)
-            assert rc == 0
+            for y0, y1 in spans:
+                rc = self.lib.orc_render_frame(C.byref(self.scene), C.byref(self.cam), _ptr(self.acc),
+                                               _ptr(self.present), C.byref(probe), C.byref(self.stats), y0, y1,
+                                               self.threads, self.trig)
+                assert rc == 0
             # the event loop's bookkeeping, main.rs:147-148
-            self.cam.frame += 1
+            self.cam.frame += self.frame_stride
             self.cam.frames_without_move = float(np.float32(self.cam.frames_without_move) + np.float32(1.0))
         return self
 

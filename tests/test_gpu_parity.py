@@ -18,35 +18,9 @@ import oracle_lib as O
 from ray_tracing_amd import (App, RT_DEBUG_BVH_INTERSECTION, RT_DEBUG_TRIANGLE_INTERSECTION, RT_OPT_COUNTERS,
                              RT_OPT_PIPELINE, RT_OPT_PROBE_HITS, default_scene)
 from ray_tracing_amd import _lib as L
+from helpers import assert_bits_equal, copy_cam, gpu_render
 
 pytestmark = pytest.mark.gpu
-
-
-def copy_cam(cam):
-    return L.CamData.from_buffer_copy(cam)
-
-
-def gpu_render(scene, cam, frames, counters=True, materials=None, pipeline=1):
-    app = App.create(copy_cam(cam), scene, device=0)
-    try:
-        app.set_option(RT_OPT_PROBE_HITS, 1)
-        app.set_option(RT_OPT_COUNTERS, int(counters))
-        app.set_option(RT_OPT_PIPELINE, pipeline)
-        if materials is not None:
-            app.set_materials(materials)
-        app.render_frames(frames)
-        out = {"acc": app.read_acc(), "present": app.read_present(), "hits": app.read_hits(), "stats": app.stats()}
-        if counters:
-            out["counters"] = app.read_counters()
-        return out
-    finally:
-        app.destroy()
-
-
-def assert_bits_equal(a, b, what):
-    a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
-    bad = a.view(np.uint32) != b.view(np.uint32)
-    assert not bad.any(), f"{what}: {int(bad.sum())} of {bad.size} words differ, first at {np.argwhere(bad)[0]}"
 
 
 @pytest.fixture(scope="module")

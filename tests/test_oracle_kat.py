@@ -1,0 +1,382 @@
+"""Pins the CPU oracle (oracle/rt_oracle.c).
+
+The reference ships no tests, vectors or fixtures (parity is unpinned by the
+reference), so the oracle is pinned from three sides instead:
+  1. known answers derived by hand from the Rust source (integer hashes,
+     closed-form colours, exactly representable geometry);
+  2. an independent NumPy restatement (np_restatement.py) that must agree bit
+     for bit on random inputs;
+  3. committed golden digests of the reference's default scene
+     (tests/golden/c1_640x360.json, made by scripts/make_golden.py).
+"""
+import ctypes as C
+import hashlib
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+import np_restatement as R
+import oracle_lib as O
+from helpers import make_manual_scene
+from ray_tracing_amd import _lib as L
+from ray_tracing_amd import default_scene
+from ray_tracing_amd.scene import SceneBuilder, affine_from_srt, bvh_params, make_cam
+
+F = np.float32
+INF_BITS = 0x7F800000
+lib = O.load()
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def fb(x):
+    return O.f32_bits(x)
+
+
+# ---------------------------------------------------------------- RNG ------
+def test_get_seed_all_zero_is_zero():
+    # h = 0 going into the avalanche stays 0 (mod.rs:17-34)
+    assert lib.orc_get_seed(0, 0, 0, 0.0, 0.0, 0.0) == 0
+
+
+def test_get_seed_hand_values():
+    # frame only: h = 0x9E3779B9, then the avalanche, by hand in Python integers
+    h = 0x9E3779B9
+    h ^= h >> 16
+    h = (h * 0x7FEB352D) & 0xFFFFFFFF
+    h ^= h >> 15
+    h = (h * 0x846CA68B) & 0xFFFFFFFF
+    h ^= h >> 16
+    assert lib.orc_get_seed(1, 0, 0, 0.0, 0.0, 0.0) == h
+    # 1.0f has bits 0x3F800000; only the red term is non-zero
+    h = (0x3F800000 * 0x27D4EB2F) & 0xFFFFFFFF
+    h ^= h >> 16
+    h = (h * 0x7FEB352D) & 0xFFFFFFFF
+    h ^= h >> 15
+    h = (h * 0x846CA68B) & 0xFFFFFFFF
+    h ^= h >> 16
+    assert lib.orc_get_seed(0, 0, 0, 1.0, 0.0, 0.0) == h
+
+
+def test_get_seed_matches_integer_restatement():
+    rng = np.random.default_rng(7)
+    for _ in range(2000):
+        frame, x, y = (int(v) for v in rng.integers(0, 2 ** 32, 3, dtype=np.uint64))
+        r, g, b = (F(v) for v in rng.standard_normal(3) * 10)
+        assert lib.orc_get_seed(frame, x, y, r, g, b) == R.get_seed(frame, x, y, r, g, b)
+
+
+def test_xor_shift_known_values():
+    assert lib.orc_xor_shift(0) == 0  # fixed point: every draw returns `lo`
+    # seed 1: x ^= x<<13 -> 0x2001; x ^= x>>17 -> 0x2001; x ^= x<<5 -> 0x2001 ^ 0x40020 = 0x42021
+    assert lib.orc_xor_shift(1) == 0x42021
+    for s in (2, 0xFFFFFFFF, 0x12345678, 0x80000000):
+        assert lib.orc_xor_shift(s) == R.xor_shift(s)
+
+
+def test_rand_float_formula_and_zero_seed():
+    s = C.c_uint32(0)
+    assert lib.orc_rand_float(C.byref(s), 3.5, 9.0) == 3.5 and s.value == 0
+    s = C.c_uint32(1)
+    v = lib.orc_rand_float(C.byref(s), -1.0, 1.0)
+    assert s.value == 0x42021
+    # 0x42021 & 65535 = 0x2021 = 8225; (8225/65535)*2 - 1 in f32
+    expect = F(8225) / F(65535.0) * (F(1.0) - F(-1.0)) + F(-1.0)
+    assert fb(v) == fb(expect)
+    rng = np.random.default_rng(3)
+    for seed in rng.integers(1, 2 ** 32, 500, dtype=np.uint64):
+        s = C.c_uint32(int(seed))
+        v = lib.orc_rand_float(C.byref(s), 0.0, 2.0 * float(R.PI))
+        ns, nv = R.rand_float(int(seed), 0.0, F(2.0) * R.PI)
+        assert s.value == ns and fb(v) == fb(nv)
+
+
+# ------------------------------------------------------- small functions ------
+def test_acos_approx_known_points():
+    # p(x) = -0.155972 x + 1.56467, times sqrt(1 - x); pi - that for negative input
+    assert fb(lib.orc_acos_approx(1.0)) == fb(0.0)
+    assert fb(lib.orc_acos_approx(0.0)) == fb(F(1.56467))
+    assert fb(lib.orc_acos_approx(-1.0)) == fb(R.PI - F(0.0))
+    half = (F(-0.155972) * F(0.5) + F(1.56467)) * np.sqrt(F(0.5))
+    assert fb(lib.orc_acos_approx(0.5)) == fb(half)
+    assert fb(lib.orc_acos_approx(-0.5)) == fb(R.PI - half)
+    for v in np.linspace(-1, 1, 401, dtype=F):
+        assert fb(lib.orc_acos_approx(v)) == fb(R.acos_approx(v))
+        assert abs(lib.orc_acos_approx(v) - math.acos(float(v))) < 1e-2  # a one-term approximation
+
+
+def test_det_sin_cos_accuracy_on_the_domain_used():
+    # phi in [0, 2 pi], theta in [0, pi] (material.rs:26-29)
+    xs = np.concatenate([np.linspace(0, 2 * math.pi + 1e-3, 20001), np.array([0.0, math.pi / 2, math.pi, 6.2831855])])
+    for x in xs.astype(F):
+        s, c = lib.orc_det_sin(x), lib.orc_det_cos(x)
+        assert abs(s - math.sin(float(x))) <= 2.5e-7
+        assert abs(c - math.cos(float(x))) <= 2.5e-7
+
+
+def test_slab_known_cases():
+    box = (O.f3(-1, -1, -1), O.f3(1, 1, 1))
+    # straight at the box from z = -5: enters at t = 4
+    assert lib.orc_hits_bounding(O.f3(0, 0, -5), O.f3(0, 0, 1), *box) in (4.0,)
+    # origin inside: t_near is negative but the box still counts as hit (t_far > 0)
+    t = lib.orc_hits_bounding(O.f3(0, 0, 0), O.f3(0.5, 0.25, 1), *box)
+    assert t == -1.0
+    # box behind the ray: t_far <= 0 -> INF
+    assert fb(lib.orc_hits_bounding(O.f3(0, 0, 5), O.f3(0, 0, 1), *box)) == INF_BITS
+    # axis-parallel ray inside the slabs: x and y lanes are -inf/+inf, no NaN
+    assert lib.orc_hits_bounding(O.f3(0.5, 0.5, -3), O.f3(0, 0, 1), *box) == 2.0
+    # axis-parallel ray exactly on a slab plane: 0/0 = NaN in that lane, f32::max/min skip it
+    assert lib.orc_hits_bounding(O.f3(1.0, 0.0, -3), O.f3(0, 0, 1), *box) == 2.0
+    # axis-parallel and outside the x slab: miss
+    assert fb(lib.orc_hits_bounding(O.f3(2, 0, -3), O.f3(0, 0, 1), *box)) == INF_BITS
+    # grazing a corner where t_near == t_far: `t_near < t_far` fails -> miss
+    assert fb(lib.orc_hits_bounding(O.f3(-2, 0, 0), O.f3(1, 1, 0), *box)) == INF_BITS
+
+
+def test_slab_matches_numpy_restatement_on_random_inputs():
+    rng = np.random.default_rng(11)
+    n_hit = 0
+    for _ in range(3000):
+        pos = (rng.standard_normal(3) * 3).astype(F)
+        d = rng.standard_normal(3).astype(F)
+        if rng.random() < 0.15:
+            d[rng.integers(0, 3)] = 0.0
+        a, b = (rng.standard_normal(3) * 2).astype(F), (rng.standard_normal(3) * 2).astype(F)
+        bmin, bmax = np.minimum(a, b), np.maximum(a, b)
+        if rng.random() < 0.1:
+            pos[0] = bmin[0]
+        got = lib.orc_hits_bounding(O.f3(*pos), O.f3(*d), O.f3(*bmin), O.f3(*bmax))
+        want = R.hits_bounding(pos, d, bmin, bmax)
+        assert fb(got) == fb(want)
+        n_hit += fb(got) != INF_BITS
+    assert 100 < n_hit < 2900
+
+
+TRI = (O.f3(-1, -1, 1), O.f3(1, -1, 1), O.f3(0, 1, 1))  # counter-clockwise seen from +z... normal = +z
+
+
+def test_triangle_known_cases():
+    eps, inf = float(R.EPS), float("inf")
+    # normal = normalize(cross(p1-p0, p2-p0)) = (0,0,1); a ray along -z meets it head on (dot < 0)
+    t = lib.orc_triangle_ray_intersect(*TRI, O.f3(0, 0, 3), O.f3(0, 0, -1), eps, inf, 1)
+    assert t == 2.0
+    # from behind (dot > 0): culled with back-face culling, hit without
+    assert fb(lib.orc_triangle_ray_intersect(*TRI, O.f3(0, 0, -1), O.f3(0, 0, 1), eps, inf, 1)) == INF_BITS
+    assert lib.orc_triangle_ray_intersect(*TRI, O.f3(0, 0, -1), O.f3(0, 0, 1), eps, inf, 0) == 2.0
+    # edge-on: |n.d| < EPS
+    assert fb(lib.orc_triangle_ray_intersect(*TRI, O.f3(-5, 0, 1), O.f3(1, 0, 0), eps, inf, 0)) == INF_BITS
+    # outside the clamp
+    assert fb(lib.orc_triangle_ray_intersect(*TRI, O.f3(0, 0, 3), O.f3(0, 0, -1), eps, 1.5, 0)) == INF_BITS
+    assert fb(lib.orc_triangle_ray_intersect(*TRI, O.f3(0, 0, 3), O.f3(0, 0, -1), 2.5, inf, 0)) == INF_BITS
+    # t == clamp upper bound is still a hit (`t > hi` rejects, hit.rs:159)
+    assert lib.orc_triangle_ray_intersect(*TRI, O.f3(0, 0, 3), O.f3(0, 0, -1), eps, 2.0, 0) == 2.0
+    # outside an edge
+    assert fb(lib.orc_triangle_ray_intersect(*TRI, O.f3(0.9, 0.9, 3), O.f3(0, 0, -1), eps, inf, 0)) == INF_BITS
+    # exactly on an edge / a vertex: `< 0` keeps it (hit.rs:169)
+    assert lib.orc_triangle_ray_intersect(*TRI, O.f3(0, -1, 3), O.f3(0, 0, -1), eps, inf, 0) == 2.0
+    assert lib.orc_triangle_ray_intersect(*TRI, O.f3(0, 1, 3), O.f3(0, 0, -1), eps, inf, 0) == 2.0
+    # zero-area triangle: the normal is NaN, every comparison is false, NaN comes back and is
+    # NOT infinite, so the caller records it (hit.rs:115, mod.rs:59-62)
+    t = lib.orc_triangle_ray_intersect(O.f3(0, 0, 1), O.f3(1, 0, 1), O.f3(2, 0, 1), O.f3(0, 0, 3), O.f3(0, 0, -1), eps,
+                                       inf, 1)
+    assert math.isnan(t) and not R.is_inf(t)
+
+
+def test_triangle_matches_numpy_restatement_on_random_inputs():
+    rng = np.random.default_rng(5)
+    hits = 0
+    for _ in range(3000):
+        p = (rng.standard_normal((3, 3)) * 2).astype(F)
+        target = (p[0] * F(0.3) + p[1] * F(0.3) + p[2] * F(0.4)) if rng.random() < 0.6 else (rng.standard_normal(3) * 2).astype(F)
+        pos = (rng.standard_normal(3) * 4).astype(F)
+        d = (target - pos).astype(F)
+        if rng.random() < 0.5:
+            d = R.normalize(d)
+        cull = int(rng.integers(0, 2))
+        t_hi = F(np.inf) if rng.random() < 0.5 else F(abs(rng.standard_normal()) * 3)
+        got = lib.orc_triangle_ray_intersect(O.f3(*p[0]), O.f3(*p[1]), O.f3(*p[2]), O.f3(*pos), O.f3(*d), float(R.EPS),
+                                             float(t_hi), cull)
+        want = R.triangle_ray_intersect(p[0], p[1], p[2], pos, d, R.EPS, t_hi, cull)
+        assert fb(got) == fb(want)
+        hits += fb(got) != INF_BITS
+    assert 200 < hits < 2800
+
+
+# --------------------------------------------------------------- BVH walk ------
+def two_triangle_scene(order):
+    """Two coplanar triangles sharing the edge x = 0, in two leaves under one root;
+    `order` says which of them is triangle 0."""
+    left = [(-2, -1, 0), (0, -1, 0), (0, 1, 0)]
+    right = [(0, -1, 0), (2, -1, 0), (0, 1, 0)]
+    tris = [left, right] if order == "left-first" else [right, left]
+    verts = np.array([p for t in tris for p in t], F)
+    idx = np.arange(6, dtype=np.uint32).reshape(2, 3)
+    return verts, idx
+
+
+def mesh_hit(scene, pos, d, cull=0, t_hi=float("inf")):
+    s = O.orc_scene(scene)
+    rec = (C.c_uint32 * 5)(0xFFFFFFFF, INF_BITS, 0, 0, 0)
+    lib.orc_mesh_hit(C.byref(s), 0, O.f3(*pos), O.f3(*d), float(R.EPS), t_hi, 7, cull, rec)
+    return {"tri": rec[0], "t": O.bits_f32(rec[1]), "inst": rec[2], "tri_tests": rec[3], "box_tests": rec[4]}
+
+
+def test_shared_edge_tie_goes_to_the_triangle_visited_later():
+    # one leaf holding both triangles; a ray through the shared edge hits both at t = 3;
+    # `t > hi` does not reject an equal t, so the later triangle overwrites (hit.rs:115-118, 159)
+    for order in ("left-first", "right-first"):
+        verts, idx = two_triangle_scene(order)
+        scene = make_manual_scene(verts, idx, [((-2, -1, -0.5), (2, 1, 0.5), 0, 1, 1)])
+        r = mesh_hit(scene, (0, 0, 3), (0, 0, -1))
+        assert r["t"] == 3.0 and r["tri"] == 1 and r["inst"] == 7
+        assert r["box_tests"] == 1 and r["tri_tests"] == 2
+
+
+def test_near_child_first_and_tie_rule():
+    verts, idx = two_triangle_scene("left-first")
+    # (a box of zero thickness can never be hit: `t_near < t_far` is strict, trace.rs:225)
+    root = ((-2, -1, -0.5), (2, 1, 0.5), 1, 2, 0)
+    leaf_l = ((-2, -1, -0.5), (0, 1, 0.5), 0, 0, 1)
+    leaf_r = ((0, -1, -0.5), (2, 1, 0.5), 1, 1, 1)
+    scene = make_manual_scene(verts, idx, [root, leaf_l, leaf_r])
+    # origin nearer to the left box: left is visited first, right afterwards; through the shared
+    # edge both hit at the same t, the later visit (right, triangle 1) wins
+    r = mesh_hit(scene, (-0.5, 0, 3), (0.5 / 3, 0, -1))
+    assert r["tri"] == 1 and r["box_tests"] == 3 and r["tri_tests"] == 2
+    # origin nearer to the right box: right first, then left wins the tie
+    r = mesh_hit(scene, (0.5, 0, 3), (-0.5 / 3, 0, -1))
+    assert r["tri"] == 0 and r["box_tests"] == 3 and r["tri_tests"] == 2
+    # equidistant centres: `d1 < d2` is false, so child 2 (right) goes first and left wins
+    r = mesh_hit(scene, (0, 0, 3), (0, 0, -1))
+    assert r["tri"] == 0 and r["box_tests"] == 3
+    # a ray that only meets the left box's triangle: the right box is still popped and tested
+    r = mesh_hit(scene, (-1, -0.5, 3), (0, 0, -1))
+    assert r["tri"] == 0 and r["t"] == 3.0 and r["box_tests"] == 3 and r["tri_tests"] == 1
+    # root missed: one box test, nothing else
+    r = mesh_hit(scene, (5, 5, 3), (0, 0, -1))
+    assert r["tri"] == 0xFFFFFFFF and r["box_tests"] == 1 and r["tri_tests"] == 0
+    # far child culled by distance after the near hit: boxes further than the hit are dropped
+    verts2 = np.array([(-1, -1, 0), (1, -1, 0), (0, 1, 0), (-1, -1, -5), (1, -1, -5), (0, 1, -5)], F)
+    idx2 = np.arange(6, dtype=np.uint32).reshape(2, 3)
+    nodes = [((-1, -1, -5.5), (1, 1, 0.5), 1, 2, 0), ((-1, -1, -0.5), (1, 1, 0.5), 0, 0, 1),
+             ((-1, -1, -5.5), (1, 1, -4.5), 1, 1, 1)]
+    r = mesh_hit(make_manual_scene(verts2, idx2, nodes), (0, 0, 3), (0, 0, -1))
+    assert r["tri"] == 0 and r["t"] == 3.0 and r["box_tests"] == 3 and r["tri_tests"] == 1
+
+
+def test_flat_box_is_never_hit():
+    verts, idx = two_triangle_scene("left-first")
+    scene = make_manual_scene(verts, idx, [((-2, -1, 0), (2, 1, 0), 0, 1, 1)])
+    r = mesh_hit(scene, (0.5, 0, 3), (0, 0, -1))
+    assert r["tri"] == 0xFFFFFFFF and r["box_tests"] == 1 and r["tri_tests"] == 0
+
+
+def test_nan_hit_of_a_zero_area_triangle_disables_later_culling():
+    # triangle 0 is degenerate (NaN recorded, clamp becomes NaN), triangle 1 is a real hit behind it
+    verts = np.array([(0, 0, 1), (1, 0, 1), (2, 0, 1), (-1, -1, 0), (1, -1, 0), (0, 1, 0)], F)
+    idx = np.arange(6, dtype=np.uint32).reshape(2, 3)
+    scene = make_manual_scene(verts, idx, [((-1, -1, -0.5), (2, 1, 1.5), 0, 1, 1)])
+    r = mesh_hit(scene, (0, 0, 3), (0, 0, -1))
+    # with a NaN clamp `t > hi` is false for the real triangle too, so it is accepted and recorded last
+    assert r["tri"] == 1 and r["t"] == 3.0
+
+
+# ------------------------------------------------------------- closed forms ------
+def test_sky_closed_form():
+    out = O.f3(0, 0, 0)
+    lib.orc_sky(O.f3(0, 1, 0), out)  # straight up: factor = clamp(1.5) = 1 -> (0.5, 0.7, 1.0)
+    assert [fb(v) for v in out] == [fb(0.5), fb(F(0.7)), fb(1.0)]
+    lib.orc_sky(O.f3(0, -2, 0), out)  # straight down: factor = clamp(-0.5) = 0 -> white
+    assert list(out) == [1.0, 1.0, 1.0]
+    lib.orc_sky(O.f3(3, 0, 0), out)  # horizon: factor = 0.5
+    want = [F(1.0) * F(0.5) + F(c) * F(0.5) for c in (0.5, 0.7, 1.0)]
+    assert [fb(v) for v in out] == [fb(w) for w in want]
+
+
+def test_default_materials_are_the_reference_constants():
+    m = L.Material()
+    lib.orc_default_material(0, C.byref(m))
+    assert (m.kind, m.backface_culling, m.ior, m.specular, m.roughness, list(m.color)) == (0, 0, 1.5, 0.0, 0.0, [1, 1, 1])
+    lib.orc_default_material(1, C.byref(m))
+    assert (m.kind, m.backface_culling) == (1, 1)
+    for i in (2, 3, 100):
+        lib.orc_default_material(i, C.byref(m))
+        assert (m.kind, m.backface_culling, list(m.color)) == (2, 1, [15, 15, 15])
+
+
+def test_affine_inverse_round_trip_on_default_scene_transforms():
+    scene, _ = default_scene(64, 36)
+    for k in range(3):
+        m = L.Affine3A.from_buffer_copy(scene.instances["transform"][k].tobytes())
+        inv, back = L.Affine3A(), L.Affine3A()
+        lib.orc_affine_inverse(C.byref(m), C.byref(inv))
+        lib.orc_affine_inverse(C.byref(inv), C.byref(back))
+        a = np.frombuffer(bytes(m), F).reshape(4, 4)[:, :3]
+        b = np.frombuffer(bytes(back), F).reshape(4, 4)[:, :3]
+        np.testing.assert_allclose(a, b, rtol=2e-6, atol=2e-6)
+        p, q = O.f3(0.3, -1.2, 2.5), O.f3(0, 0, 0)
+        w = O.f3(0, 0, 0)
+        lib.orc_transform_point3(C.byref(m), p, w)
+        lib.orc_transform_point3(C.byref(inv), w, q)
+        np.testing.assert_allclose(list(q), list(p), rtol=1e-5, atol=1e-5)
+    # scale 10, identity rotation: the inverse is exactly 1/10 on the diagonal
+    m = L.Affine3A.from_buffer_copy(scene.instances["transform"][1].tobytes())
+    inv = L.Affine3A()
+    lib.orc_affine_inverse(C.byref(m), C.byref(inv))
+    # t0 = cross(Y, Z) = (100,0,0); det = 1000; r = 1/1000; 100 * r
+    assert fb(inv.x_axis[0]) == fb(F(100.0) * (F(1.0) / F(1000.0)))
+
+
+def test_camera_ray_centre_and_corner():
+    cam = make_cam(640, 360)
+    pos, d = O.f3(0, 0, 0), O.f3(0, 0, 0)
+    lib.orc_camera_ray(C.byref(cam), 320.0, 180.0, pos, d)
+    assert list(pos) == [0, 0, -20] and list(d) == [0, 0, 1]
+    lib.orc_camera_ray(C.byref(cam), 0.0, 0.0, pos, d)
+    e = F(math.tan(float((F(90.0) * R.PI / F(180.0)) / F(2.0))))  # libm tan of the f32 half angle
+    e = F(np.tan(F((F(90.0) * R.PI / F(180.0)) / F(2.0))))
+    assert abs(d[0] + float(e)) < 1e-6 and abs(d[1] + float(e) * 360 / 640) < 1e-6 and d[2] == 1.0
+
+
+def test_emissive_and_sky_pixels_of_the_default_scene_in_closed_form():
+    """Pixel (0, 0) of frame 0 has seed 0, so no jitter, and its ray leaves through the
+    box's edge into the sky; emissive pixels carry 15 * sqrt(|cos|) exactly."""
+    scene, cam = default_scene(640, 360)
+    r = O.OracleRenderer(scene, cam, trig=O.TRIG_DET).render(1)
+    assert r.hit_triangle[0, 0] == 0xFFFFFFFF
+    pos, d = O.f3(0, 0, 0), O.f3(0, 0, 0)
+    lib.orc_camera_ray(C.byref(cam), 0.0, 0.0, pos, d)
+    n = R.normalize(np.array(list(d), F))
+    n = R.normalize(n)  # trace.rs:191 then trace.rs:73
+    sky = O.f3(0, 0, 0)
+    lib.orc_sky(O.f3(*n), sky)
+    assert [fb(v) for v in r.acc[0, 0, :3]] == [fb(v) for v in sky]
+    assert r.acc[0, 0, 3] == 1.0
+    em = r.hit_instance == 2
+    assert em.sum() > 500
+    v = r.acc[em][:, :3]
+    assert np.all(v[:, 0] == v[:, 1]) and np.all(v[:, 1] == v[:, 2]) and np.all(v <= 15.0) and np.all(v >= 0.0)
+
+
+# -------------------------------------------------------------- golden digests ------
+def digest(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def test_default_scene_golden_digests():
+    """Config 1 (640x360, frame 0, zeroed accumulator, then 3 more chained frames)."""
+    with open(os.path.join(GOLDEN, "c1_640x360.json")) as f:
+        gold = json.load(f)
+    scene, cam = default_scene(640, 360)
+    assert digest(scene.triangles) == gold["scene"]["triangles"]
+    assert digest(scene.bvh) == gold["scene"]["bvh"]
+    r = O.OracleRenderer(scene, cam, trig=O.TRIG_DET).render(1)
+    got = {"hit_triangle": digest(r.hit_triangle), "hit_instance": digest(r.hit_instance),
+           "hit_t_bits": digest(r.hit_t_bits), "box_tests": digest(r.box_tests),
+           "triangle_tests": digest(r.triangle_tests), "acc": digest(r.acc)}
+    assert got == gold["frame0"]
+    assert r.stats_dict() == gold["stats_frame0"]
+    r.render(3)
+    assert digest(r.acc) == gold["acc_after_4_frames"]
