@@ -1,0 +1,23 @@
+#!/bin/bash
+# Runs on the GPU box (via gpurun): kernel-trace stats plus separate PMC passes of
+# `bench.py --steps 3 --warmup 1 --no-cpu-baseline`.  Output under gpurun_out/$1.
+set -u
+TAG=${1:-prof}
+OUT=gpurun_out/$TAG
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+BENCH="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $BENCH > "$OUT/bench_trace.json" 2> "$OUT/trace.err" || exit 1
+pass() {  # name, counters...
+    local name=$1; shift
+    timeout -s KILL 200 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/pmc_$name" -- $BENCH > "$OUT/bench_$name.json" 2> "$OUT/pmc_$name.err" || exit 1
+}
+pass sq1 SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY
+pass sq2 SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_BUSY_CYCLES SQ_INST_LEVEL_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE
+pass tcc1 TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_DRAM_sum
+pass tcc2 TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_HIT_sum TCC_MISS_sum
+pass fetch FETCH_SIZE
+pass write WRITE_SIZE
+pass tcp TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_READ_sum TCP_TCC_WRITE_REQ_sum
+pass grbm GRBM_GUI_ACTIVE GRBM_COUNT
+echo profile done
