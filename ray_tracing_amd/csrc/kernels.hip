@@ -208,6 +208,7 @@ __global__ __launch_bounds__(kBlock) void path_kernel_persistent(DevScene sc, De
     float4 it0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), it1 = it0, it2 = it0, it3 = it0;  // the pending item
     uint32_t node = 0;  // ST_DESC: index of the node held in the item
     uint32_t tri_i = 0, tri_last = 0, sp = 0;
+    bool sp_counted = false;  // ST_POP: the pending record came off the stack (its test is already counted)
 
     while (phase != ST_DEAD) {
         const float4* next = nullptr;
@@ -287,6 +288,7 @@ __global__ __launch_bounds__(kBlock) void path_kernel_persistent(DevScene sc, De
                         next = reinterpret_cast<const float4*>(&in);
                         sp = 0;
                         phase = ST_POP;
+                        sp_counted = false;
                         break;
                     }
                     // every instance has been visited: the rest of trace_ray, trace.rs:97-172
@@ -348,6 +350,10 @@ __global__ __launch_bounds__(kBlock) void path_kernel_persistent(DevScene sc, De
                 }
             } else {
                 float4 lo, hi;
+                bool far_alive = false;  // ST_DESC: the farther child is worth visiting at all
+                float far_dist = RT_INF;
+                uint32_t far_ref = 0;
+                float4 flo = it0, fhi = it1;
                 if (phase == ST_DESC) {
                     // the item is an internal node that passed its test: hit.rs:88-107
                     V3 c1 = (v3(it0.x, it0.y, it0.z) + v3(it1.x, it1.y, it1.z)) * 0.5f;
@@ -355,17 +361,39 @@ __global__ __launch_bounds__(kBlock) void path_kernel_persistent(DevScene sc, De
                     V3 e1 = c1 - lpos, e2 = c2 - lpos;
                     bool first_is_1 = dot(e1, e1) < dot(e2, e2);
                     if (COUNT) rec.internal_visits += 1;
-                    stack[sp * kBlock] = (node << 1) | (first_is_1 ? 1u : 0u);  // the farther child's slot
-                    sp += 1;
                     lo = first_is_1 ? it0 : it2;
                     hi = first_is_1 ? it1 : it3;
+                    flo = first_is_1 ? it2 : it0;
+                    fhi = first_is_1 ? it3 : it1;
+                    far_ref = (node << 1) | (first_is_1 ? 1u : 0u);  // the farther child's slot
+                    // The reference tests the farther child when it pops it.  A ray that misses
+                    // that box altogether misses it whenever it is popped, so that outcome is
+                    // taken now and the entry is never pushed; a box that IS hit still waits on
+                    // the stack and is tested again at pop time against the clamp of that moment.
+                    far_dist = hits_bounding(lpos, ldir, flo, fhi);
+                    far_alive = far_dist != RT_INF;
+                    if (COUNT) rec.box_tests += 1;
                 } else {
                     lo = it0;  // the item is the child record itself
                     hi = it1;
                 }
                 // the node on top of the reference's stack: hit.rs:77-86
-                if (COUNT) rec.box_tests += 1;
-                const bool alive = !culled(hits_bounding(lpos, ldir, lo, hi), t_hi);
+                if (COUNT && !(phase == ST_POP && sp_counted)) rec.box_tests += 1;
+                bool alive = !culled(hits_bounding(lpos, ldir, lo, hi), t_hi);
+                if (phase == ST_DESC) {
+                    if (alive) {
+                        if (far_alive) {
+                            stack[sp * kBlock] = far_ref;
+                            sp += 1;
+                        }
+                    } else if (far_alive) {
+                        // the nearer child is out: the reference pops the farther one next,
+                        // with the clamp unchanged
+                        alive = !(far_dist > t_hi);
+                        lo = flo;
+                        hi = fhi;
+                    }
+                }
                 const uint32_t a = __float_as_uint(lo.w), b = __float_as_uint(hi.w);
                 if (!alive) {
                     finished = true;
@@ -394,6 +422,7 @@ __global__ __launch_bounds__(kBlock) void path_kernel_persistent(DevScene sc, De
                         cull = in.cull != 0u;
                         next = reinterpret_cast<const float4*>(&in);
                         phase = ST_POP;
+                        sp_counted = false;
                     } else {
                         ctl = CT_NEXT_INSTANCE;  // shade
                         phase = ST_CONTROL;
@@ -402,6 +431,7 @@ __global__ __launch_bounds__(kBlock) void path_kernel_persistent(DevScene sc, De
                     sp -= 1;
                     uint32_t ref = stack[sp * kBlock];
                     phase = ST_POP;
+                    sp_counted = true;
                     next = reinterpret_cast<const float4*>(&sc.nodes[ref >> 1].c[ref & 1u]);
                 }
             }
