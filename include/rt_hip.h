@@ -196,6 +196,12 @@ void rt_affine_inverse(const rt_affine3a* m, rt_affine3a* out);
 void rt_cam_update_pos(rt_cam_data* cam, const float delta[3]);
 void rt_cam_update_mouse(rt_cam_data* cam, float orientation[2], float mouse_x, float mouse_y);
 
+/* Self-test of the library's "divide by a cached reciprocal" routine, which the
+ * slab test uses in place of six IEEE divisions per box: draws n (numerator,
+ * divisor) pairs in the routine's operand range from `seed` and returns how many
+ * quotients differ in any bit from the IEEE quotient a / d.  Must return 0. */
+uint64_t rt_selftest_div_by_rcp(uint64_t n, uint64_t seed);
+
 const char* rt_version(void);
 
 #ifdef __cplusplus

@@ -94,6 +94,7 @@ struct DevScene {
     const DevObject* objects;
     const DevInstance* instances;
     uint32_t n_instances;
+    uint32_t fast_div;  // every box coordinate is 0 or has 2^-24 <= |b| <= 2^24 (see fastdiv.hpp)
 };
 
 struct DevStats {

@@ -2,6 +2,7 @@
 
 #include <cstring>
 
+#include "fastdiv.hpp"
 #include "host_math.hpp"
 #include "host_scene.hpp"
 
@@ -124,6 +125,11 @@ bool build_gpu_scene(const rt_scene_info& info, const rt_vertex* vertices, size_
     }
 
     // internal nodes get dense indices in input order
+    out.fast_div = true;
+    for (size_t i = 0; i < n_bvh; ++i)
+        for (int k = 0; k < 3; ++k)
+            if (!div_term_ok(bvh[i].bounding_box.min[k]) || !div_term_ok(bvh[i].bounding_box.max[k])) out.fast_div = false;
+
     std::vector<uint32_t> dense(n_bvh, 0);
     uint32_t n_internal = 0;
     for (size_t i = 0; i < n_bvh; ++i)

@@ -18,6 +18,7 @@ struct GpuScene {
     std::vector<DevObject> objects;
     std::vector<DevInstance> instances;
     uint32_t max_depth = 0;  // longest root-to-leaf path in nodes, over all objects
+    bool fast_div = true;    // all box coordinates are in the range fastdiv.hpp asks for
 };
 
 constexpr uint32_t kMaxBvhDepth = 65;  // deepest tree any kernel variant has stack for

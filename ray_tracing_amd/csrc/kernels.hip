@@ -203,6 +203,7 @@ __global__ __launch_bounds__(kBlock) void path_kernel_persistent(DevScene sc, De
     record_new(rec);
     // traversal state of the current (segment, instance)
     V3 lpos = ray.pos, ldir = ray.dir;
+    DirRcp rcp = make_dir_rcp(lpos, ldir, false);
     float t_hi = RT_INF;
     bool cull = false;
     float4 it0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), it1 = it0, it2 = it0, it3 = it0;  // the pending item
@@ -283,6 +284,7 @@ __global__ __launch_bounds__(kBlock) void path_kernel_persistent(DevScene sc, De
                         const DevInstance& in = sc.instances[inst];
                         lpos = xf_point(in.inv, ray.pos);
                         ldir = xf_vector(in.inv, ray.dir);
+                        rcp = make_dir_rcp(lpos, ldir, sc.fast_div != 0u);
                         t_hi = rec.t;
                         cull = in.cull != 0u;
                         next = reinterpret_cast<const float4*>(&in);
@@ -349,6 +351,9 @@ __global__ __launch_bounds__(kBlock) void path_kernel_persistent(DevScene sc, De
                     next = reinterpret_cast<const float4*>(&sc.tris[tri_i]);
                 }
             } else {
+                // wave-uniform: the plain division is right for every lane, the reciprocal form only
+                // for lanes whose operands are in range, so one out-of-range lane switches the wave
+                const bool all_fast = __ballot(!rcp.ok) == 0ull;
                 float4 lo, hi;
                 bool far_alive = false;  // ST_DESC: the farther child is worth visiting at all
                 float far_dist = RT_INF;
@@ -370,7 +375,7 @@ __global__ __launch_bounds__(kBlock) void path_kernel_persistent(DevScene sc, De
                     // that box altogether misses it whenever it is popped, so that outcome is
                     // taken now and the entry is never pushed; a box that IS hit still waits on
                     // the stack and is tested again at pop time against the clamp of that moment.
-                    far_dist = hits_bounding(lpos, ldir, flo, fhi);
+                    far_dist = all_fast ? hits_bounding_rcp(lpos, ldir, rcp, flo, fhi) : hits_bounding(lpos, ldir, flo, fhi);
                     far_alive = far_dist != RT_INF;
                     if (COUNT) rec.box_tests += 1;
                 } else {
@@ -379,7 +384,8 @@ __global__ __launch_bounds__(kBlock) void path_kernel_persistent(DevScene sc, De
                 }
                 // the node on top of the reference's stack: hit.rs:77-86
                 if (COUNT && !(phase == ST_POP && sp_counted)) rec.box_tests += 1;
-                bool alive = !culled(hits_bounding(lpos, ldir, lo, hi), t_hi);
+                const float dist = all_fast ? hits_bounding_rcp(lpos, ldir, rcp, lo, hi) : hits_bounding(lpos, ldir, lo, hi);
+                bool alive = !culled(dist, t_hi);
                 if (phase == ST_DESC) {
                     if (alive) {
                         if (far_alive) {
@@ -418,6 +424,7 @@ __global__ __launch_bounds__(kBlock) void path_kernel_persistent(DevScene sc, De
                         const DevInstance& in = sc.instances[inst];
                         lpos = xf_point(in.inv, ray.pos);
                         ldir = xf_vector(in.inv, ray.dir);
+                        rcp = make_dir_rcp(lpos, ldir, sc.fast_div != 0u);
                         t_hi = rec.t;
                         cull = in.cull != 0u;
                         next = reinterpret_cast<const float4*>(&in);

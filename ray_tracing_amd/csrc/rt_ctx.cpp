@@ -30,6 +30,7 @@ struct rt_ctx {
     std::vector<DevInstance> h_instances;
     uint32_t n_instances = 0;
     uint32_t max_depth = 0;
+    bool fast_div = false;
 
     // frame buffers, sized for the current canvas
     uint32_t W = 0, H = 0;
@@ -175,7 +176,7 @@ int render(rt_ctx* c, const rt_cam_data& cam, uint32_t n_frames) {
     if (rc != RT_OK) return rc;
     if (n_frames == 0) return RT_OK;
 
-    DevScene sc{c->d_nodes, c->d_tris, c->d_objects, c->d_instances, c->n_instances};
+    DevScene sc{c->d_nodes, c->d_tris, c->d_objects, c->d_instances, c->n_instances, c->fast_div ? 1u : 0u};
     DevCam dc = make_cam(cam, c->frame_stride, c->seed_mode);
     DevRows rows;
     rows.strip_h = c->world > 1 ? c->strip_h : cam.canvas_height;
@@ -206,7 +207,12 @@ int render(rt_ctx* c, const rt_cam_data& cam, uint32_t n_frames) {
         q.w_ctl = c->vote_w[0];
         q.w_box = c->vote_w[1];
         q.w_leaf = c->vote_w[2];
-        const uint32_t n_blocks = (uint32_t)(c->n_cus * persistent_blocks_per_cu(stack_needed, count));
+        int per_cu = persistent_blocks_per_cu(stack_needed, count);
+        if (const char* e = std::getenv("RT_BLOCKS_PER_CU")) {  // tuning knob: fewer resident workgroups
+            int v = std::atoi(e);
+            if (v >= 1 && v < per_cu) per_cu = v;
+        }
+        const uint32_t n_blocks = (uint32_t)(c->n_cus * per_cu);
         RT_HIP(c, launch_persistent_kernel(sc, dc, rows, fr, q, n_frames, stack_needed, count, n_blocks, c->stream));
     }
     RT_HIP(c, hipEventRecord(c->ev1, c->stream));
@@ -329,6 +335,7 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_info* info, const rt_vertex* verti
     c->h_instances = g.instances;
     c->n_instances = (uint32_t)g.instances.size();
     c->max_depth = g.max_depth;
+    c->fast_div = g.fast_div && std::getenv("RT_NO_FAST_DIV") == nullptr;
     c->have_scene = true;
     return RT_OK;
 }

@@ -5,6 +5,7 @@
 #include <vector>
 
 #include "../../include/rt_hip.h"
+#include "fastdiv.hpp"
 #include "host_math.hpp"
 #include "host_scene.hpp"
 
@@ -178,6 +179,45 @@ void rt_cam_update_mouse(rt_cam_data* cam, float orientation[2], float mouse_x, 
     float sy = std::sin(hy), cy = std::cos(hy), sx = std::sin(hx), cx = std::cos(hx);
     float q[4] = {cy * sx, sy * cx, -sy * sx, cy * cx};
     cam->transform = affine_from_srt(scale, q, ld(cam->transform.translation));
+}
+
+uint64_t rt_selftest_div_by_rcp(uint64_t n, uint64_t seed) {
+    // splitmix64 stream -> operands: random sign and mantissa, exponents spread over the
+    // whole admitted range, numerators formed as differences like the slab test forms them
+    auto next = [&seed]() {
+        seed += 0x9E3779B97F4A7C15ull;
+        uint64_t z = seed;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        return z ^ (z >> 31);
+    };
+    auto make = [&next](int lo_exp, int hi_exp) {
+        uint64_t r = next();
+        uint32_t mant = uint32_t(r) & 0x7FFFFFu;
+        uint32_t sign = uint32_t(r >> 63) << 31;
+        int e = lo_exp + int((r >> 32) % uint64_t(hi_exp - lo_exp));  // value in [2^e, 2^(e+1))
+        uint32_t bits = sign | (uint32_t(e + 127) << 23) | mant;
+        float f;
+        std::memcpy(&f, &bits, 4);
+        return f;
+    };
+    uint64_t bad = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        float d = make(-24, 24);
+        float b = (i % 7 == 0) ? 0.0f : make(-24, 24);
+        float p = (i % 11 == 0) ? 0.0f : ((i % 3 == 0) ? b * (1.0f + float(int(next() % 64) - 32) * 1.1920929e-7f) : make(-24, 24));
+        if (!div_den_ok(d) || !div_term_ok(b) || !div_term_ok(p)) continue;
+        float a = b - p;
+        float r = 1.0f / d;
+        float want = a / d;
+        float got = div_by_rcp(a, d, r);
+        if (a == 0.0f) {
+            if (got != 0.0f) ++bad;  // a zero quotient; its sign is not part of the contract
+        } else if (std::memcmp(&want, &got, 4) != 0) {
+            ++bad;
+        }
+    }
+    return bad;
 }
 
 }  // extern "C"

@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 
 #include "device_types.hpp"
+#include "fastdiv.hpp"
 
 #pragma clang fp contract(off)
 
@@ -155,9 +156,7 @@ RT_DEV Ray camera_ray(const DevCam& cam, float px, float py) {
 }
 
 // ---- slab test: trace.rs:208-229 --------------------------------------------------
-RT_DEV float hits_bounding(V3 pos, V3 dir, float4 lo, float4 hi) {
-    float nx = (lo.x - pos.x) / dir.x, ny = (lo.y - pos.y) / dir.y, nz = (lo.z - pos.z) / dir.z;
-    float fx = (hi.x - pos.x) / dir.x, fy = (hi.y - pos.y) / dir.y, fz = (hi.z - pos.z) / dir.z;
+RT_DEV float slab_finish(float nx, float ny, float nz, float fx, float fy, float fz) {
     bool sx = nx > fx, sy = ny > fy, sz = nz > fz;
     float ax = sx ? fx : nx, bx = sx ? nx : fx;
     float ay = sy ? fy : ny, by = sy ? ny : fy;
@@ -165,6 +164,38 @@ RT_DEV float hits_bounding(V3 pos, V3 dir, float4 lo, float4 hi) {
     float t_near = fmaxf(ax, fmaxf(ay, az));
     float t_far = fminf(bx, fminf(by, bz));
     return (t_near < RT_INF && t_near < t_far && t_far > 0.0f) ? t_near : RT_INF;
+}
+
+RT_DEV float hits_bounding(V3 pos, V3 dir, float4 lo, float4 hi) {
+    float nx = (lo.x - pos.x) / dir.x, ny = (lo.y - pos.y) / dir.y, nz = (lo.z - pos.z) / dir.z;
+    float fx = (hi.x - pos.x) / dir.x, fy = (hi.y - pos.y) / dir.y, fz = (hi.z - pos.z) / dir.z;
+    return slab_finish(nx, ny, nz, fx, fy, fz);
+}
+
+// Reciprocals of one traversal's ray direction.  `ok` says that origin and
+// direction satisfy the range conditions of div_by_rcp (fastdiv.hpp); the
+// condition on the box coordinates is a property of the scene (DevScene::fast_div).
+struct DirRcp {
+    float x, y, z;
+    bool ok;
+};
+RT_DEV DirRcp make_dir_rcp(V3 pos, V3 dir, bool scene_ok) {
+    DirRcp r;
+    r.x = 1.0f / dir.x;
+    r.y = 1.0f / dir.y;
+    r.z = 1.0f / dir.z;
+    r.ok = scene_ok && div_den_ok(dir.x) && div_den_ok(dir.y) && div_den_ok(dir.z) && div_term_ok(pos.x) &&
+           div_term_ok(pos.y) && div_term_ok(pos.z);
+    return r;
+}
+
+// hits_bounding with the six quotients formed by div_by_rcp: same bits.
+RT_DEV float hits_bounding_rcp(V3 pos, V3 dir, const DirRcp& rcp, float4 lo, float4 hi) {
+    float nx = div_by_rcp(lo.x - pos.x, dir.x, rcp.x), ny = div_by_rcp(lo.y - pos.y, dir.y, rcp.y),
+          nz = div_by_rcp(lo.z - pos.z, dir.z, rcp.z);
+    float fx = div_by_rcp(hi.x - pos.x, dir.x, rcp.x), fy = div_by_rcp(hi.y - pos.y, dir.y, rcp.y),
+          fz = div_by_rcp(hi.z - pos.z, dir.z, rcp.z);
+    return slab_finish(nx, ny, nz, fx, fy, fz);
 }
 
 // ---- triangle: hit.rs:137-191, plane precomputed per triangle --------------------

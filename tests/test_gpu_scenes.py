@@ -162,6 +162,37 @@ def test_deep_tree_uses_the_large_stack():
         check_against_oracle(scene, ortho_like_cam(160, 32, z=7.0, fov=90.0), frames=2, pipeline=pipeline)
 
 
+def parse_obj(name):
+    data = S._resource(name).encode()
+    lib = L.load()
+    nv, nt = C.c_size_t(0), C.c_size_t(0)
+    lib.rt_parse_obj(data, len(data), None, C.byref(nv), None, C.byref(nt))
+    v = np.zeros(nv.value, S.VERTEX_DT)
+    t = np.zeros((nt.value, 3), np.uint32)
+    lib.rt_parse_obj(data, len(data), S._ptr(v), C.byref(nv), S._ptr(t), C.byref(nt))
+    return v["pos"].copy(), t
+
+
+def test_coordinates_outside_the_reciprocal_division_range():
+    """The slab test divides by cached reciprocals only while box coordinates, ray origin and
+    direction are 0 or within [2^-24, 2^24]; outside it uses plain divisions.  Results are
+    bit-exact either way."""
+    base, cam = default_scene(96, 54)
+    for k in (2.0 ** 28, 2.0 ** -28):
+        b = S.SceneBuilder()
+        for idx, name in enumerate(("default_cube.obj", "cornel_box.obj", "teapot.obj")):
+            # object space scaled by k, instance transform by 1/k: the same world-space scene
+            t = L.Affine3A.from_buffer_copy(base.instances["transform"][idx].tobytes())
+            for axis in (t.x_axis, t.y_axis, t.z_axis):
+                for i in range(3):
+                    axis[i] = float(F(axis[i]) / F(k))
+            v, f = parse_obj(name)
+            b.add_mesh(v * F(k), f, [t])
+        check_against_oracle(b.build(), cam, frames=2)
+    # a tiny canvas whose centre column looks straight down the axis
+    check_against_oracle(base, S.make_cam(9, 9), frames=1)
+
+
 def test_invalid_scenes_are_rejected_before_any_launch():
     verts = np.array([(-1, -1, 0), (1, -1, 0), (0, 1, 0)], F)
     idx = np.array([[0, 1, 2]], np.uint32)

@@ -300,3 +300,12 @@ def test_scene_builder_rejects_bad_input():
         b.add_mesh(np.zeros((3, 3), F), np.array([[0, 1, 5]], np.uint32), [ident])  # index out of range
     with pytest.raises(L.RtError):
         b.add_obj_file("v 0 0 0\n", [ident])  # no faces
+
+
+# ------------------------------------------------------- arithmetic self-test ------
+def test_division_by_cached_reciprocal_is_the_ieee_quotient():
+    """The slab test's six divisions share three divisors per traversal; the library forms the
+    quotients from cached reciprocals with two FMA corrections.  Over the whole operand range
+    it admits, the result must be the correctly rounded quotient, bit for bit."""
+    assert lib.rt_selftest_div_by_rcp(3_000_000, 1) == 0
+    assert lib.rt_selftest_div_by_rcp(3_000_000, 0xDEADBEEF) == 0
