@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """Throughput of the trace path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config c3]
 
-Workload (BASELINE.json configs[2], the one the Mrays/s metric and its 1/2/4/8
-GPU figures are quoted on): a seeded ~1.0 M-triangle procedural scene at
+Default workload = BASELINE.json configs[2], the one the Mrays/s metric and its
+1/2/4/8-GPU figures are quoted on: a seeded ~1.0 M-triangle procedural scene at
 1920x1080, 16 accumulated one-sample frames per step, depth 10, scene resident
 in HBM before the timed region.  With N > 1 (launched by torch.distributed.run,
 one process per GPU) the canvas is dealt to the ranks in interleaved 8-row
@@ -13,10 +13,14 @@ image whatever N is ("strong" scaling).  A ray is one trace_ray invocation
 (shader/src/modules/trace.rs:195), primary and secondary alike; the count comes
 from the device's own counter.
 
+Other configs of BASELINE.json, for reference numbers (not the driver's bench
+line): c2 (10k tessellated spheres, 1 spp, 5 segments), c4 (10 M triangles, 4K,
+256 spp split by sample index over the GPUs with one RCCL all-reduce of the
+accumulator per step), c5 (closed box, diffuse, 9 segments).
+
 Prints ONE JSON line on rank 0.
 """
 import argparse
-import ctypes as C
 import json
 import os
 import sys
@@ -25,11 +29,16 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
-WIDTH, HEIGHT, FRAMES_PER_STEP, DEPTH = 1920, 1080, 16, 10
 STRIP_H = 8
+
+CONFIGS = {
+    # name: (width, height, frames per step, depth, partition)
+    "c2": (1920, 1080, 1, 5, "tile"),
+    "c3": (1920, 1080, 16, 10, "tile"),
+    "c4": (3840, 2160, 256, 10, "sample"),
+    "c5": (1920, 1080, 4, 9, "tile"),
+}
 
 
 def algorithmic_bytes(stats, n_instances):
@@ -43,11 +52,35 @@ def algorithmic_bytes(stats, n_instances):
             + (80 * n_instances + 56) * stats["rays"] + 32 * stats["paths"])
 
 
-def cpu_baseline(scene, cam, budget_s=12.0):
+def build_scene(name, leaf_max, threads, grid):
+    from ray_tracing_amd import sphere_field_scene, terrain_scene
+
+    w, h, frames, depth, _ = CONFIGS[name]
+    if name == "c2":
+        scene, cam = sphere_field_scene(w, h, n_spheres=10000, seed=1, subdivisions=2, depth=depth, threads=threads,
+                                        leaf_max=leaf_max)
+        what = "10000 tessellated spheres (icosphere, 320 triangles each), diffuse instance under the sky"
+    elif name == "c3":
+        scene, cam = terrain_scene(w, h, n=grid, depth=depth, threads=threads, leaf_max=leaf_max)
+        what = "procedural terrain, 3 instances (glass / diffuse / emissive)"
+    elif name == "c4":
+        scene, cam = terrain_scene(w, h, n=2236 if grid == 700 else grid, depth=depth, threads=threads,
+                                   leaf_max=leaf_max)
+        what = "procedural terrain, 3 instances (glass / diffuse / emissive)"
+    else:
+        scene, cam = terrain_scene(w, h, n=grid, depth=depth, closed_box=True, light=False, threads=threads,
+                                   leaf_max=leaf_max)
+        what = "procedural terrain inside a closed box, diffuse only"
+    workload = (f"{what}, {scene.n_triangles} triangles, {w}x{h}, {frames} spp per step, depth {depth}, "
+                f"BVH by the reference's split rule with leaves of at most {leaf_max} triangles")
+    return scene, cam, workload
+
+
+def cpu_baseline(scene, cam, frames_cap, budget_s=12.0):
     """The CPU oracle (a port of the reference's arithmetic: the reference itself has
     no CPU path and no Rust toolchain exists here) on the same scene and seeds,
-    timed on this box's host cores on a bounded sample: whole 1080p frames of the
-    same chained sequence until the budget is spent."""
+    timed on this box's host cores on a bounded sample: whole frames of the same
+    chained sequence until the budget is spent."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
 
@@ -58,12 +91,12 @@ def cpu_baseline(scene, cam, budget_s=12.0):
         r.render(1)
         frames += 1
         dt = time.perf_counter() - t0
-        if dt > budget_s or frames >= FRAMES_PER_STEP:
+        if dt > budget_s or frames >= frames_cap:
             break
     s = r.stats_dict()
     return {"value": s["rays"] / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": f"{frames} full {WIDTH}x{HEIGHT} one-sample frames of the same scene, camera and seed chain "
-                      f"({s['rays']} rays in {dt:.2f} s)"}, r
+            "sample": f"{frames} full {cam.canvas_width}x{cam.canvas_height} one-sample frames of the same scene, "
+                      f"camera and seed chain ({s['rays']} rays in {dt:.2f} s)"}
 
 
 def main():
@@ -71,6 +104,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--grid", type=int, default=700, help="terrain grid resolution (700 -> ~1.0 M triangles)")
     ap.add_argument("--leaf-max", type=int, default=4,
@@ -92,32 +126,54 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    from ray_tracing_amd import App, RT_OPT_COUNTERS, RT_OPT_PIPELINE, terrain_scene
+    from ray_tracing_amd import (App, RT_OPT_COUNTERS, RT_OPT_FRAME_STRIDE, RT_OPT_PIPELINE, RT_OPT_SEED_MODE)
     from ray_tracing_amd import _lib as L
+    from ray_tracing_amd.distributed import reduce_samples, sample_split
 
-    threads = min(os.cpu_count() or 1, 16)
-    scene, cam0 = terrain_scene(WIDTH, HEIGHT, n=args.grid, depth=DEPTH, threads=max(1, threads // max(1, world)),
-                                leaf_max=args.leaf_max)
+    width, height, frames_per_step, depth, partition = CONFIGS[args.config]
+    threads = max(1, min(os.cpu_count() or 1, 16) // max(1, world))
+    scene, cam0, workload = build_scene(args.config, args.leaf_max, threads, args.grid)
     n_inst = int(scene.info.num_instances)
 
-    def fresh_cam():
-        return L.CamData.from_buffer_copy(cam0)
-
     stream = torch.cuda.current_stream().cuda_stream
-    app = App.create(fresh_cam(), scene, device=local_rank, stream=stream)
-    app.set_rows(STRIP_H, rank, world)
+    app = App.create(L.CamData.from_buffer_copy(cam0), scene, device=local_rank, stream=stream)
     app.set_option(RT_OPT_PIPELINE, args.pipeline)
+    if partition == "tile":
+        app.set_rows(STRIP_H, rank, world)
+        first_frame, my_frames = 0, frames_per_step
+        how = f"interleaved {STRIP_H}-row strips over {world} GPU(s), no collective"
+    else:
+        first_frame, stride, my_frames = sample_split(frames_per_step, rank, world)
+        app.set_option(RT_OPT_FRAME_STRIDE, stride)
+        app.set_option(RT_OPT_SEED_MODE, 1)
+        how = (f"samples split by index over {world} GPU(s) (independent-seed variant), one sum all-reduce of the "
+               f"{width * height * 16 / 1e6:.0f} MB accumulator per step")
+    acc_view = app.acc_tensor() if partition == "sample" else None
+
+    def fresh_cam():
+        cam = L.CamData.from_buffer_copy(cam0)
+        cam.frame = first_frame
+        return cam
 
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def one_step():
-        # a step = the whole 16-sample job from a zeroed accumulator
+    def launch():
+        app.render_frames(my_frames)
+
+    def one_step(events=None):
+        # a step = the whole job from a zeroed accumulator
         app.cam_data = fresh_cam()
         app.clear_acc()
-        app.render_frames(FRAMES_PER_STEP)
+        if events:
+            events[0].record()
+        launch()
+        if events:
+            events[1].record()
+        if acc_view is not None:
+            reduce_samples(acc_view)  # RCCL over xGMI; the one exchange this mode has
 
     # --- counter pass (untimed): the reference's debug counters for one step --------------
     app.set_option(RT_OPT_COUNTERS, 1)
@@ -137,38 +193,29 @@ def main():
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
     for k in range(args.steps):
-        app.cam_data = fresh_cam()
-        app.clear_acc()
-        ev[k][0].record()
-        app.render_frames(FRAMES_PER_STEP)
-        ev[k][1].record()
+        one_step(ev[k])
     sync()
     elapsed = time.perf_counter() - t0
-    last_ms = sum(a.elapsed_time(b) for a, b in ev) / max(1, args.steps)  # average kernel time per launch
+    kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / max(1, args.steps)  # average kernel time per launch
     stats = app.stats()
 
     t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    r = torch.tensor([float(stats["rays"]), float(algorithmic_bytes(counted, n_inst)), last_ms],
-                     dtype=torch.float64, device="cuda")
+    r = torch.tensor([float(stats["rays"])], dtype=torch.float64, device="cuda")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        rmax = r.clone()
         dist.all_reduce(r, op=dist.ReduceOp.SUM)
-        dist.all_reduce(rmax, op=dist.ReduceOp.MAX)
-    else:
-        rmax = r
     elapsed = float(t.item())
     total_rays = float(r[0].item())
     ms_per_step = elapsed / args.steps * 1e3
 
-    def measured_traffic(workload):
+    def measured_traffic():
         """HBM-side bytes per launch from the committed rocprofv3 PMC passes of this very
         workload (profiles/traffic_bench.json); None when no matching profile exists."""
         try:
             with open(os.path.join(ROOT, "profiles", "traffic_bench.json")) as f:
-                t = json.load(f)
-            if t["workload"] == workload and t["n_gpus"] == world:
-                return t["traffic_bytes_per_launch"]
+                tr = json.load(f)
+            if tr["workload"] == workload and tr["n_gpus"] == world:
+                return tr["traffic_bytes_per_launch"]
         except (OSError, KeyError, ValueError):
             pass
         return None
@@ -177,29 +224,24 @@ def main():
     if rank == 0:
         # roofline of the one kernel of the step, on this rank's share of the work
         rank_bytes = float(algorithmic_bytes(counted, n_inst))
-        kernel_s = last_ms * 1e-3
-        achieved = rank_bytes / kernel_s / 1e9
-        workload = (f"procedural terrain, {scene.n_triangles} triangles, {WIDTH}x{HEIGHT}, "
-                    f"{FRAMES_PER_STEP} spp per step, depth {DEPTH}, 3 instances "
-                    f"(glass / diffuse / emissive), BVH by the reference's split rule with "
-                    f"leaves of at most {args.leaf_max} triangles")
+        achieved = rank_bytes / (kernel_ms * 1e-3) / 1e9
         out = {
             "metric": "Mrays/s (primary+secondary)", "value": total_rays / elapsed / 1e6, "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "ms_per_frame": ms_per_step / FRAMES_PER_STEP,
+            "ms_per_frame": ms_per_step / frames_per_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": workload,
-                       "partition": f"interleaved {STRIP_H}-row strips over {world} GPU(s), no collective",
+            "config": {"workload": workload, "name": args.config, "partition": how,
                        "rays_per_step": total_rays / args.steps},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(workload),
-                         "kernel": "path_kernel", "kernel_ms": last_ms,
-                         "algorithmic_bytes_per_launch": rank_bytes,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(),
+                         "kernel": "path_kernel_persistent" if args.pipeline else "path_kernel",
+                         "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": rank_bytes,
                          "counters_per_launch": counted, "schedule_per_launch": sched},
         }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"], _ = cpu_baseline(scene, fresh_cam())
+        cam = L.CamData.from_buffer_copy(cam0)
+        out["cpu_baseline"] = cpu_baseline(scene, cam, frames_cap=max(frames_per_step, 64))
     app.destroy()
     if world > 1:
         dist.barrier()

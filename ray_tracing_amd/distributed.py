@@ -37,6 +37,8 @@ def gather_strips(local_image, strip_h, group=None, dst=0):
     import torch
     import torch.distributed as dist
 
+    if not (dist.is_available() and dist.is_initialized()):
+        return local_image.clone()
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     h = local_image.shape[0]
@@ -62,7 +64,7 @@ def reduce_samples(acc, group=None):
     one all-reduce of 4*W*H floats (1080p: 33 MB, 4K: 133 MB)."""
     import torch.distributed as dist
 
-    if dist.get_world_size(group) > 1:
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=group)
     return acc
 

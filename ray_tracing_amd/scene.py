@@ -75,13 +75,15 @@ def affine_from_columns(x, y, z, t):
 
 def look_at(eye, target, up=(0.0, 1.0, 0.0)):
     """Camera-to-world transform whose +z axis points from eye to target
-    (the reference's camera looks down +z, trace.rs:34)."""
+    (the reference's camera looks down +z, trace.rs:34).  Pixel row 0 is the top of
+    the image and maps to the NEGATIVE camera y (trace.rs:30), so the camera's y
+    axis points down in the world."""
     eye = np.asarray(eye, np.float64)
     f = np.asarray(target, np.float64) - eye
     f /= np.linalg.norm(f)
     r = np.cross(np.asarray(up, np.float64), f)
     r /= np.linalg.norm(r)
-    u = np.cross(f, r)
+    u = -np.cross(f, r)
     return affine_from_columns(r.astype(np.float32), u.astype(np.float32), f.astype(np.float32),
                                eye.astype(np.float32))
 
