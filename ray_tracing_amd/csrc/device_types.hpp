@@ -49,23 +49,26 @@ struct alignas(64) DevObject {
     DevChild unused;  // pads the record to the 64 bytes of a DevNode
 };
 
-// The first 64 bytes have the shape of a DevNode whose child 0 is the root of
-// the instance's object, so "start traversing this instance" is an ordinary
-// item fetch (slot 0).
+// Three 64-byte lines.  The first is all that "move the ray into this
+// instance's space" needs, so that step is an ordinary 64-byte item fetch; the
+// second starts with a copy of the object's root record, which is the 32-byte
+// item "start traversing this instance" fetches.
 struct alignas(64) DevInstance {
+    float inv[12];   // inverse transform: X, Y, Z, T  (object <- world)
+    uint32_t cull;
+    uint32_t pad0[3];
     DevChild root;   // copy of the object's root record
     uint32_t object_id;
     uint32_t mat_kind;
-    uint32_t cull;
     float specular;
-    float color[3];
     float specular_roughness;
-    float inv[12];   // inverse transform: X, Y, Z, T  (object <- world)
-    float fwd[12];   // transform:         X, Y, Z, T  (world <- object)
+    float color[3];
     float roughness;
+    float fwd[12];   // transform:         X, Y, Z, T  (world <- object)
     float ior;
-    uint32_t pad[6];
+    uint32_t pad1[3];
 };
+static_assert(sizeof(DevInstance) == 192, "three 64-byte lines");
 
 struct DevCam {
     float X[3], Y[3], Z[3], T[3];  // camera-to-world
@@ -100,9 +103,9 @@ struct DevScene {
 struct DevStats {
     unsigned long long rays, box_tests, internal_visits, triangle_tests, paths;
     // scheduling profile of the persistent kernel (only with counters on):
-    // wave iterations that ran a control / box / triangle step, and the lanes
-    // that took part in them
-    unsigned long long iters[3], lanes[3];
+    // wave iterations that ran a control / box / triangle / instance set-up step,
+    // the lanes that took part in them and the cycles they took
+    unsigned long long iters[4], lanes[4], cycles[4];
 };
 
 // Work queues of the persistent kernel: 8 ranges of 64-pixel items (8x8 tiles),
@@ -111,7 +114,7 @@ struct DevQueue {
     uint32_t* head;          // 8 counters, 32 words apart; zeroed before every launch
     uint32_t first_item[9];  // queue i covers items [first_item[i], first_item[i + 1])
     uint32_t tiles_x;        // 8x8 tiles per row of tiles
-    int w_ctl, w_box, w_leaf;  // vote weights of the three kinds of step
+    int w_ctl, w_box, w_leaf, w_setup;  // vote weights of the four kinds of step
 };
 
 struct DevFrame {

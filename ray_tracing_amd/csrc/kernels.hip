@@ -155,10 +155,10 @@ __global__ __launch_bounds__(kBlock) void path_kernel(DevScene sc, DevCam cam, D
 //    internal node, a 64-byte triangle, or the 32-byte record of a popped child
 //    or of an object's root).  The load of the item is issued at the end of one step and
 //    consumed by the next, so a lane never has two dependent fetches in a step.
-//  * A step is one of three kinds: CONTROL (generate a path, start a segment,
-//    set up the next instance, or shade + accumulate after the last instance),
-//    BOX (test the child box on top of the reference's stack, descend or pop)
-//    and LEAF (test one triangle).  Per iteration the wave runs only the kind
+//  * A step is one of four kinds: CONTROL (generate a path, start a segment, or
+//    shade + accumulate after the last instance), SETUP (move the ray into the
+//    next instance's space), BOX (test the child box on top of the reference's
+//    stack, descend or pop) and LEAF (test one triangle).  Per iteration the wave runs only the kind
 //    most of its lanes are waiting for; the others keep their item and wait.
 //    No lane ever idles until its neighbours finish a leaf, a subtree, an
 //    instance, a bounce or a frame.
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(kBlock) void path_kernel(DevScene sc, DevCam cam, D
 //    covering a contiguous range of 8x8 pixel tiles; a wave that drains its own
 //    queue moves on to the next one.
 // ---------------------------------------------------------------------------
-enum : uint32_t { ST_CONTROL = 0, ST_DESC = 1, ST_POP = 2, ST_LEAF = 3, ST_DEAD = 4 };
+enum : uint32_t { ST_CONTROL = 0, ST_DESC = 1, ST_POP = 2, ST_LEAF = 3, ST_DEAD = 4, ST_SETUP = 5 };
 enum : uint32_t { CT_NEW_PIXEL = 0, CT_NEW_PATH = 1, CT_START_SEGMENT = 2, CT_NEXT_INSTANCE = 3 };
 
 template <int STACK_N, bool COUNT>
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(kBlock) void path_kernel_persistent(DevScene sc, De
     const unsigned long long lanes_below = (1ull << lane) - 1ull;
 
     unsigned long long n_rays = 0, n_box = 0, n_internal = 0, n_tri = 0, n_paths = 0;
-    unsigned long long sched_iters[3] = {0, 0, 0}, sched_lanes[3] = {0, 0, 0};  // wave-uniform
+    unsigned long long sched_iters[4] = {0, 0, 0, 0}, sched_lanes[4] = {0, 0, 0, 0}, sched_cycles[4] = {0, 0, 0, 0};  // wave-uniform
 
     uint32_t phase = n_frames > 0 ? ST_CONTROL : ST_DEAD;
     uint32_t ctl = CT_NEW_PIXEL;
@@ -213,14 +213,20 @@ __global__ __launch_bounds__(kBlock) void path_kernel_persistent(DevScene sc, De
 
     while (phase != ST_DEAD) {
         const float4* next = nullptr;
+        const unsigned long long t_begin = COUNT ? __builtin_readcyclecounter() : 0ull;
         // wave-uniform choice of the one kind of step this iteration runs
         const int w_ctl = __popcll(__ballot(phase == ST_CONTROL)) * q.w_ctl;
         const int w_box = __popcll(__ballot(phase == ST_DESC || phase == ST_POP)) * q.w_box;
         const int w_leaf = __popcll(__ballot(phase == ST_LEAF)) * q.w_leaf;
-        const int pick = (w_box >= w_leaf && w_box >= w_ctl) ? 1 : (w_leaf >= w_ctl ? 2 : 0);
+        const int w_setup = __popcll(__ballot(phase == ST_SETUP)) * q.w_setup;
+        int pick = 1, w_best = w_box;
+        if (w_leaf > w_best) pick = 2, w_best = w_leaf;
+        if (w_setup > w_best) pick = 3, w_best = w_setup;
+        if (w_ctl > w_best) pick = 0;
         if (COUNT) {
             sched_iters[pick] += 1;
-            sched_lanes[pick] += (unsigned)((pick == 0 ? w_ctl / q.w_ctl : pick == 1 ? w_box / q.w_box : w_leaf / q.w_leaf));
+            sched_lanes[pick] += (unsigned)(pick == 0 ? w_ctl / q.w_ctl : pick == 1 ? w_box / q.w_box
+                                            : pick == 2 ? w_leaf / q.w_leaf : w_setup / q.w_setup);
         }
 
         if (pick == 0) {
@@ -280,17 +286,8 @@ __global__ __launch_bounds__(kBlock) void path_kernel_persistent(DevScene sc, De
                         ctl = CT_NEXT_INSTANCE;
                     }
                     if (inst < sc.n_instances) {
-                        // trace.rs:76-94: the ray in the instance's object space, clamp (EPS, record.t)
-                        const DevInstance& in = sc.instances[inst];
-                        lpos = xf_point(in.inv, ray.pos);
-                        ldir = xf_vector(in.inv, ray.dir);
-                        rcp = make_dir_rcp(lpos, ldir, sc.fast_div != 0u);
-                        t_hi = rec.t;
-                        cull = in.cull != 0u;
-                        next = reinterpret_cast<const float4*>(&in);
-                        sp = 0;
-                        phase = ST_POP;
-                        sp_counted = false;
+                        next = reinterpret_cast<const float4*>(&sc.instances[inst]);
+                        phase = ST_SETUP;
                         break;
                     }
                     // every instance has been visited: the rest of trace_ray, trace.rs:97-172
@@ -331,6 +328,21 @@ __global__ __launch_bounds__(kBlock) void path_kernel_persistent(DevScene sc, De
                     }
                     ctl = CT_NEW_PATH;
                 }
+            }
+        } else if (pick == 3) {
+            if (phase == ST_SETUP) {
+                // trace.rs:76-94: the ray in the instance's object space, clamp (EPS, record.t).
+                // The item is the first line of the DevInstance: the inverse transform and the cull flag.
+                const float m[12] = {it0.x, it0.y, it0.z, it0.w, it1.x, it1.y, it1.z, it1.w, it2.x, it2.y, it2.z, it2.w};
+                lpos = xf_point(m, ray.pos);
+                ldir = xf_vector(m, ray.dir);
+                rcp = make_dir_rcp(lpos, ldir, sc.fast_div != 0u);
+                t_hi = rec.t;
+                cull = __float_as_uint(it3.x) != 0u;
+                next = reinterpret_cast<const float4*>(&sc.instances[inst].root);
+                sp = 0;
+                phase = ST_POP;
+                sp_counted = false;
             }
         } else if ((pick == 2 && phase == ST_LEAF) || (pick == 1 && (phase == ST_DESC || phase == ST_POP))) {
             bool finished = false;  // this lane has to pop (or the instance is done)
@@ -420,16 +432,8 @@ __global__ __launch_bounds__(kBlock) void path_kernel_persistent(DevScene sc, De
                 if (sp == 0) {
                     inst += 1;  // this instance is done, trace.rs:76
                     if (inst < sc.n_instances) {
-                        // set up the next one at once: it needs no other lane's company
-                        const DevInstance& in = sc.instances[inst];
-                        lpos = xf_point(in.inv, ray.pos);
-                        ldir = xf_vector(in.inv, ray.dir);
-                        rcp = make_dir_rcp(lpos, ldir, sc.fast_div != 0u);
-                        t_hi = rec.t;
-                        cull = in.cull != 0u;
-                        next = reinterpret_cast<const float4*>(&in);
-                        phase = ST_POP;
-                        sp_counted = false;
+                        next = reinterpret_cast<const float4*>(&sc.instances[inst]);
+                        phase = ST_SETUP;
                     } else {
                         ctl = CT_NEXT_INSTANCE;  // shade
                         phase = ST_CONTROL;
@@ -451,12 +455,14 @@ __global__ __launch_bounds__(kBlock) void path_kernel_persistent(DevScene sc, De
                 it3 = next[3];
             }
         }
+        if (COUNT) sched_cycles[pick] += __builtin_readcyclecounter() - t_begin;
     }
     flush_stats(fr, COUNT, lane, n_rays, n_paths, n_box, n_internal, n_tri);
     if (COUNT && lane == 0 && fr.stats) {
-        for (int k = 0; k < 3; ++k) {
+        for (int k = 0; k < 4; ++k) {
             atomicAdd(&fr.stats->iters[k], sched_iters[k]);
             atomicAdd(&fr.stats->lanes[k], sched_lanes[k]);
+            atomicAdd(&fr.stats->cycles[k], sched_cycles[k]);
         }
     }
 }

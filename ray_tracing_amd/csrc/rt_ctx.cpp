@@ -44,7 +44,7 @@ struct rt_ctx {
     DevStats* d_stats = nullptr;
     uint32_t* d_queue = nullptr;  // work-queue heads of the persistent kernel
     int n_cus = 0;
-    int vote_w[3] = {2, 1, 3};  // vote weights: control, box, triangle steps
+    int vote_w[4] = {2, 1, 3, 2};  // vote weights: control, box, triangle, instance set-up steps
 
     // options
     int pipeline = 1;
@@ -207,6 +207,7 @@ int render(rt_ctx* c, const rt_cam_data& cam, uint32_t n_frames) {
         q.w_ctl = c->vote_w[0];
         q.w_box = c->vote_w[1];
         q.w_leaf = c->vote_w[2];
+        q.w_setup = c->vote_w[3];
         int per_cu = persistent_blocks_per_cu(stack_needed, count);
         if (const char* e = std::getenv("RT_BLOCKS_PER_CU")) {  // tuning knob: fewer resident workgroups
             int v = std::atoi(e);
@@ -251,11 +252,12 @@ int rt_create(int device, rt_ctx** out) {
     if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return bail("hipGetDeviceProperties", e);
     c->n_cus = prop.multiProcessorCount;
     if (const char* w = std::getenv("RT_VOTE_WEIGHTS")) {
-        int a = 1, b = 1, d = 1;
-        if (std::sscanf(w, "%d,%d,%d", &a, &b, &d) == 3 && a > 0 && b > 0 && d > 0) {
+        int a = 1, b = 1, d = 1, s = 1;
+        if (std::sscanf(w, "%d,%d,%d,%d", &a, &b, &d, &s) == 4 && a > 0 && b > 0 && d > 0 && s > 0) {
             c->vote_w[0] = a;
             c->vote_w[1] = b;
             c->vote_w[2] = d;
+            c->vote_w[3] = s;
         }
     }
     *out = c;
@@ -471,9 +473,10 @@ int rt_get_sched_stats(rt_ctx* c, rt_sched_stats* out) {
     RT_HIP(c, hipSetDevice(c->device));
     RT_HIP(c, hipMemcpyAsync(&s, c->d_stats, sizeof s, hipMemcpyDeviceToHost, c->stream));
     RT_HIP(c, hipStreamSynchronize(c->stream));
-    for (int k = 0; k < 3; ++k) {
+    for (int k = 0; k < 4; ++k) {
         out->iterations[k] = s.iters[k];
         out->lanes[k] = s.lanes[k];
+        out->cycles[k] = s.cycles[k];
     }
     return RT_OK;
 }
