@@ -204,6 +204,14 @@ void rt_cam_update_mouse(rt_cam_data* cam, float orientation[2], float mouse_x, 
  * divisor) pairs in the routine's operand range from `seed` and returns how many
  * quotients differ in any bit from the IEEE quotient a / d.  Must return 0. */
 uint64_t rt_selftest_div_by_rcp(uint64_t n, uint64_t seed);
+/* Self-test of the slab test's shortcut: box tests are first decided from
+ * approximate quotients (numerator times cached reciprocal) and only fall back to
+ * exact quotients when a comparison is not clear-cut.  Draws n (ray, box, clamp)
+ * cases from `seed`, many of them with near-ties, and returns how many cases the
+ * shortcut called clear-cut yet decided differently from the exact test (hit or
+ * miss, and beyond the clamp or not).  Must return 0.  *n_clear receives the number
+ * of cases that were called clear-cut. */
+uint64_t rt_selftest_slab_filter(uint64_t n, uint64_t seed, uint64_t* n_clear);
 
 const char* rt_version(void);
 

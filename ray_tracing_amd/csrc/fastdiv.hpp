@@ -62,4 +62,54 @@ RT_HD float div_by_rcp(float a, float d, float r) {
     return __builtin_fmaf(e, r, q);
 }
 
+// ---------------------------------------------------------------------------
+// The slab test decided from approximate quotients.
+//
+// The slab test (trace.rs:208-229) only COMPARES its six quotients: with each
+// other (t_near < t_far), with zero (t_far > 0) and, in the caller, with the
+// clamp (t_near > t_hi).  Under the range conditions above, q = RN(a * r) has
+// the sign of the IEEE quotient t = RN(a / d), is zero exactly when t is, and
+// |q - t| < 2^-22 |q|  (r is within 2^-24 relative of 1/d, the product rounds
+// once more, t is within 2^-24 of a/d).  Maxima and minima of such values keep
+// that bound (the larger of two approximations is within 2^-22 of the larger
+// of the two exact values), and the sign of min-of-max is preserved term by
+// term.  So with T_near, T_far the exact values and tn, tf the approximate
+// ones:
+//     |tf - tn| > 2^-21 (|tn| + |tf|)   =>  (T_near < T_far) == (tn < tf)
+//     (T_far > 0) == (tf > 0)           always
+//     |tn - t_hi| > 2^-21 |tn|          =>  (T_near > t_hi) == (tn > t_hi)
+// When either premise fails (ties included: a flat box, whose two planes give
+// one and the same quotient, always lands here when the ray crosses it) the
+// test is "ambiguous" and the caller evaluates the exact quotients instead.
+// The margins carry a factor 2 of slack over the bound.
+struct SlabApprox {
+    float t_near, t_far;
+};
+
+constexpr float kSlabMargin = 4.76837158203125e-07f;  // 2^-21
+
+RT_HD SlabApprox slab_approx(float lox, float loy, float loz, float hix, float hiy, float hiz, float px, float py,
+                             float pz, float rx, float ry, float rz) {
+    float nx = (lox - px) * rx, ny = (loy - py) * ry, nz = (loz - pz) * rz;
+    float fx = (hix - px) * rx, fy = (hiy - py) * ry, fz = (hiz - pz) * rz;
+    SlabApprox s;
+    s.t_near = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(nx, fx), __builtin_fminf(ny, fy)), __builtin_fminf(nz, fz));
+    s.t_far = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(nx, fx), __builtin_fmaxf(ny, fy)), __builtin_fmaxf(nz, fz));
+    return s;
+}
+
+// Written so that a NaN anywhere (a NaN clamp) reads as ambiguous.
+RT_HD bool slab_ambiguous(SlabApprox s, float t_hi) {
+    float an = __builtin_fabsf(s.t_near), af = __builtin_fabsf(s.t_far);
+    bool clear_order = __builtin_fabsf(s.t_far - s.t_near) > kSlabMargin * (an + af);
+    bool clear_clamp = __builtin_fabsf(s.t_near - t_hi) > kSlabMargin * an;
+    return !(clear_order && clear_clamp);
+}
+
+// The value hits_bounding would return, good for comparisons only: the entry
+// distance when the box is hit, +inf when it is not.
+RT_HD float slab_dist(SlabApprox s) {
+    return (s.t_near < s.t_far && s.t_far > 0.0f) ? s.t_near : __builtin_huge_valf();
+}
+
 }  // namespace rt

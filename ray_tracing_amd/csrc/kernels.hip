@@ -363,40 +363,58 @@ __global__ __launch_bounds__(kBlock) void path_kernel_persistent(DevScene sc, De
                     next = reinterpret_cast<const float4*>(&sc.tris[tri_i]);
                 }
             } else {
-                // wave-uniform: the plain division is right for every lane, the reciprocal form only
-                // for lanes whose operands are in range, so one out-of-range lane switches the wave
-                const bool all_fast = __ballot(!rcp.ok) == 0ull;
-                float4 lo, hi;
-                bool far_alive = false;  // ST_DESC: the farther child is worth visiting at all
-                float far_dist = RT_INF;
+                const bool desc = phase == ST_DESC;
+                float4 lo = it0, hi = it1;    // ST_POP: the item is the child record itself
+                float4 flo = it0, fhi = it1;  // ST_DESC: the farther child
                 uint32_t far_ref = 0;
-                float4 flo = it0, fhi = it1;
-                if (phase == ST_DESC) {
+                if (desc) {
                     // the item is an internal node that passed its test: hit.rs:88-107
                     V3 c1 = (v3(it0.x, it0.y, it0.z) + v3(it1.x, it1.y, it1.z)) * 0.5f;
                     V3 c2 = (v3(it2.x, it2.y, it2.z) + v3(it3.x, it3.y, it3.z)) * 0.5f;
                     V3 e1 = c1 - lpos, e2 = c2 - lpos;
                     bool first_is_1 = dot(e1, e1) < dot(e2, e2);
-                    if (COUNT) rec.internal_visits += 1;
                     lo = first_is_1 ? it0 : it2;
                     hi = first_is_1 ? it1 : it3;
                     flo = first_is_1 ? it2 : it0;
                     fhi = first_is_1 ? it3 : it1;
                     far_ref = (node << 1) | (first_is_1 ? 1u : 0u);  // the farther child's slot
-                    // The reference tests the farther child when it pops it.  A ray that misses
-                    // that box altogether misses it whenever it is popped, so that outcome is
-                    // taken now and the entry is never pushed; a box that IS hit still waits on
-                    // the stack and is tested again at pop time against the clamp of that moment.
-                    far_dist = all_fast ? hits_bounding_rcp(lpos, ldir, rcp, flo, fhi) : hits_bounding(lpos, ldir, flo, fhi);
-                    far_alive = far_dist != RT_INF;
-                    if (COUNT) rec.box_tests += 1;
-                } else {
-                    lo = it0;  // the item is the child record itself
-                    hi = it1;
+                    if (COUNT) {
+                        rec.internal_visits += 1;
+                        rec.box_tests += 1;  // the farther child, tested below
+                    }
                 }
                 // the node on top of the reference's stack: hit.rs:77-86
                 if (COUNT && !(phase == ST_POP && sp_counted)) rec.box_tests += 1;
-                const float dist = all_fast ? hits_bounding_rcp(lpos, ldir, rcp, lo, hi) : hits_bounding(lpos, ldir, lo, hi);
+                // Three ways to the same decisions, chosen per wave.  The plain division is right
+                // for every lane; quotients through the cached reciprocal need the lane's operands
+                // in range; approximate quotients also need every comparison to be clear-cut.
+                // One lane outside a premise moves the whole wave to the next, dearer form.
+                float dist = RT_INF, far_dist = RT_INF;
+                bool decided = false;
+                const bool all_fast = __ballot(!rcp.ok) == 0ull;
+                if (all_fast) {
+                    SlabApprox sn = slab_approx(lo.x, lo.y, lo.z, hi.x, hi.y, hi.z, lpos.x, lpos.y, lpos.z, rcp.x, rcp.y, rcp.z);
+                    SlabApprox sf = slab_approx(flo.x, flo.y, flo.z, fhi.x, fhi.y, fhi.z, lpos.x, lpos.y, lpos.z, rcp.x, rcp.y, rcp.z);
+                    if (__ballot(slab_ambiguous(sn, t_hi) || (desc && slab_ambiguous(sf, t_hi))) == 0ull) {
+                        dist = slab_dist(sn);
+                        far_dist = slab_dist(sf);
+                        decided = true;
+                    }
+                }
+                if (!decided) {
+                    if (all_fast) {
+                        dist = hits_bounding_rcp(lpos, ldir, rcp, lo, hi);
+                        far_dist = hits_bounding_rcp(lpos, ldir, rcp, flo, fhi);
+                    } else {
+                        dist = hits_bounding(lpos, ldir, lo, hi);
+                        far_dist = hits_bounding(lpos, ldir, flo, fhi);
+                    }
+                }
+                // The reference tests the farther child when it pops it.  A ray that misses
+                // that box altogether misses it whenever it is popped, so that outcome is
+                // taken now and the entry is never pushed; a box that IS hit still waits on
+                // the stack and is tested again at pop time against the clamp of that moment.
+                const bool far_alive = desc && far_dist != RT_INF;
                 bool alive = !culled(dist, t_hi);
                 if (phase == ST_DESC) {
                     if (alive) {

@@ -220,4 +220,88 @@ uint64_t rt_selftest_div_by_rcp(uint64_t n, uint64_t seed) {
     return bad;
 }
 
+uint64_t rt_selftest_slab_filter(uint64_t n, uint64_t seed, uint64_t* n_clear) {
+    auto next = [&seed]() {
+        seed += 0x9E3779B97F4A7C15ull;
+        uint64_t z = seed;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        return z ^ (z >> 31);
+    };
+    auto unit = [&next]() { return float(next() >> 40) * (1.0f / 16777216.0f); };  // [0, 1)
+    auto signed_pow2 = [&](int lo_exp, int hi_exp) {  // +-[2^lo, 2^hi), log-uniform
+        float m = 1.0f + unit();
+        float v = std::ldexp(m, lo_exp + int(next() % uint64_t(hi_exp - lo_exp)));
+        return (next() & 1) ? -v : v;
+    };
+    auto nudge = [&](float v, int ulps) {
+        for (int i = 0; i < (ulps < 0 ? -ulps : ulps); ++i) v = std::nextafter(v, ulps < 0 ? -INFINITY : INFINITY);
+        return v;
+    };
+    uint64_t bad = 0, clear = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        float p[3], d[3], r[3], lo[3], hi[3];
+        bool ok = true;
+        for (int k = 0; k < 3; ++k) {
+            p[k] = (next() % 8 == 0) ? 0.0f : signed_pow2(-6, 10);
+            d[k] = (next() % 4 == 0) ? signed_pow2(-20, -6) : signed_pow2(-6, 1);
+            r[k] = 1.0f / d[k];
+            ok = ok && div_den_ok(d[k]) && div_term_ok(p[k]);
+        }
+        // a box around a point of the ray; some corners ON the ray (near-ties between axes),
+        // some boxes flat (exact ties between the two planes of an axis)
+        float s = (next() % 8 == 0) ? -std::ldexp(1.0f + unit(), int(next() % 8) - 2) : std::ldexp(1.0f + unit(), int(next() % 12) - 4);
+        int kind = int(next() % 6);
+        for (int k = 0; k < 3; ++k) {
+            float c = p[k] + d[k] * s;
+            float e0 = std::ldexp(unit(), int(next() % 10) - 6), e1 = std::ldexp(unit(), int(next() % 10) - 6);
+            if (kind == 0) e0 = 0.0f;                           // the corner lo lies on the ray
+            if (kind == 1) e1 = 0.0f;                           // the corner hi lies on the ray
+            if (kind == 2 && k == int(i % 3)) e0 = e1 = 0.0f;   // flat along one axis, crossed by the ray
+            lo[k] = c - e0;
+            hi[k] = c + e1;
+            if (kind == 3 && k == int(i % 3)) hi[k] = lo[k];    // flat, usually missed
+            if (kind == 4) {                                    // a corner a few ulps off the ray
+                lo[k] = nudge(c, int(next() % 9) - 4);
+                hi[k] = lo[k] + e1;
+            }
+            ok = ok && div_term_ok(lo[k]) && div_term_ok(hi[k]);
+        }
+        if (!ok) continue;
+        // the exact test, trace.rs:208-229
+        float q[6];
+        for (int k = 0; k < 3; ++k) {
+            q[k] = (lo[k] - p[k]) / d[k];
+            q[3 + k] = (hi[k] - p[k]) / d[k];
+        }
+        float t_near = -INFINITY, t_far = INFINITY;
+        for (int k = 0; k < 3; ++k) {
+            float a = q[k], b = q[3 + k];
+            if (a > b) std::swap(a, b);
+            t_near = std::fmax(t_near, a);
+            t_far = std::fmin(t_far, b);
+        }
+        bool hit = t_near < INFINITY && t_near < t_far && t_far > 0.0f;
+        float t_hi;
+        switch (next() % 4) {
+            case 0: t_hi = INFINITY; break;
+            case 1: t_hi = nudge(t_near, int(next() % 17) - 8); break;
+            case 2: t_hi = t_near; break;
+            default: t_hi = std::ldexp(1.0f + unit(), int(next() % 14) - 5); break;
+        }
+        SlabApprox a = slab_approx(lo[0], lo[1], lo[2], hi[0], hi[1], hi[2], p[0], p[1], p[2], r[0], r[1], r[2]);
+        if (slab_ambiguous(a, t_hi)) continue;
+        ++clear;
+        float dist = slab_dist(a);
+        bool hit_a = dist != INFINITY;
+        if (hit_a != hit) {
+            ++bad;
+        } else if (hit && ((dist > t_hi) != (t_near > t_hi))) {
+            ++bad;
+        }
+    }
+    if (n_clear) *n_clear = clear;
+    return bad;
+}
+
 }  // extern "C"

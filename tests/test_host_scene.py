@@ -309,3 +309,14 @@ def test_division_by_cached_reciprocal_is_the_ieee_quotient():
     it admits, the result must be the correctly rounded quotient, bit for bit."""
     assert lib.rt_selftest_div_by_rcp(3_000_000, 1) == 0
     assert lib.rt_selftest_div_by_rcp(3_000_000, 0xDEADBEEF) == 0
+
+
+def test_slab_shortcut_never_decides_differently_when_it_calls_a_case_clear():
+    """Box tests are first decided from approximate quotients; cases with a comparison that is
+    not clear-cut (ties, near-ties) go to the exact quotients.  Whatever the shortcut calls
+    clear-cut must be decided exactly as trace.rs:208-229 decides it, and the shortcut must
+    not be vacuous: most random cases are clear-cut, the constructed near-ties are not."""
+    for seed in (1, 0xC0FFEE):
+        clear = C.c_uint64(0)
+        assert lib.rt_selftest_slab_filter(2_000_000, seed, C.byref(clear)) == 0
+        assert 400_000 < clear.value < 1_900_000
