@@ -212,6 +212,15 @@ uint64_t rt_selftest_div_by_rcp(uint64_t n, uint64_t seed);
  * miss, and beyond the clamp or not).  Must return 0.  *n_clear receives the number
  * of cases that were called clear-cut. */
 uint64_t rt_selftest_slab_filter(uint64_t n, uint64_t seed, uint64_t* n_clear);
+/* Self-test of the triangle test's shortcut: whether the plane hit point lies
+ * inside the triangle is first read off three approximate edge functions and the
+ * exact cross products are only evaluated when a sign is not clear-cut.  Draws n
+ * (triangle, point) cases from `seed`, most of them with the point on or within
+ * a few units in the last place of an edge or a vertex, and returns how many
+ * cases the shortcut called clear-cut yet decided differently from the exact
+ * evaluation of hit.rs:160-188.  Must return 0.  *n_clear receives the number of
+ * cases that were called clear-cut. */
+uint64_t rt_selftest_tri_filter(uint64_t n, uint64_t seed, uint64_t* n_clear);
 
 const char* rt_version(void);
 

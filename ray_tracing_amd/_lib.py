@@ -137,6 +137,7 @@ SIGNATURES = {
     "rt_cam_update_mouse": (None, [_P(CamData), _P(_f), _f, _f]),
     "rt_selftest_div_by_rcp": (C.c_uint64, [C.c_uint64, C.c_uint64]),
     "rt_selftest_slab_filter": (C.c_uint64, [C.c_uint64, C.c_uint64, _P(C.c_uint64)]),
+    "rt_selftest_tri_filter": (C.c_uint64, [C.c_uint64, C.c_uint64, _P(C.c_uint64)]),
 }
 
 _lib = None

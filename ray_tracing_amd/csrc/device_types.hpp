@@ -44,6 +44,16 @@ struct alignas(64) DevTri {
     float d;     float pad[3];
 };
 
+// What the persistent kernel's triangle step reads: the same plane, the first
+// vertex, and the edge functions of trifilter.hpp.  The full DevTri is only
+// fetched when that shortcut cannot decide.
+struct alignas(64) DevTriTest {
+    float n[3];  float d;             // plane, same bits as DevTri's
+    float p0[3]; float c1;            // first vertex; constant of the second edge function
+    float m0[3]; float margin_scale;  // n x (p1 - p0); 2^-18 * e_len
+    float m1[3]; float e_len;         // n x (p2 - p1); bound on the 1-norm of the edges
+};
+
 struct alignas(64) DevObject {
     DevChild root;  // the object's root box and what the root is
     DevChild unused;  // pads the record to the 64 bytes of a DevNode
@@ -94,6 +104,7 @@ struct DevRows {
 struct DevScene {
     const DevNode* nodes;
     const DevTri* tris;
+    const DevTriTest* tri_tests;  // same numbering as tris
     const DevObject* objects;
     const DevInstance* instances;
     uint32_t n_instances;

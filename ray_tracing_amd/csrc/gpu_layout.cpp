@@ -5,6 +5,7 @@
 #include "fastdiv.hpp"
 #include "host_math.hpp"
 #include "host_scene.hpp"
+#include "trifilter.hpp"
 
 namespace rt {
 
@@ -103,6 +104,7 @@ bool build_gpu_scene(const rt_scene_info& info, const rt_vertex* vertices, size_
 
     // triangles: gather the vertices, precompute the plane (hit.rs:145-148)
     out.tris.resize(n_triangles);
+    out.tri_tests.resize(n_triangles);
     for (size_t i = 0; i < n_triangles; ++i) {
         const rt_tri& t = triangles[i];
         if (t.i0 >= n_vertices || t.i1 >= n_vertices || t.i2 >= n_vertices) {
@@ -122,6 +124,8 @@ bool build_gpu_scene(const rt_scene_info& info, const rt_vertex* vertices, size_
         o.nz = normal.z;
         o.d = d;
         o.pad[0] = o.pad[1] = o.pad[2] = 0.0f;
+        const float nf[3] = {normal.x, normal.y, normal.z};
+        tri_filter_build(o.p0, o.p1, o.p2, nf, d, out.tri_tests[i]);
     }
 
     // internal nodes get dense indices in input order

@@ -15,6 +15,7 @@ namespace rt {
 struct GpuScene {
     std::vector<DevNode> nodes;  // one per INTERNAL reference node
     std::vector<DevTri> tris;    // one per triangle, same numbering as the input
+    std::vector<DevTriTest> tri_tests;  // one per triangle
     std::vector<DevObject> objects;
     std::vector<DevInstance> instances;
     uint32_t max_depth = 0;  // longest root-to-leaf path in nodes, over all objects

@@ -3,6 +3,7 @@
 
 #include "kernels.hpp"
 #include "trace_device.hpp"
+#include "trifilter.hpp"
 
 namespace rt {
 
@@ -347,8 +348,30 @@ __global__ __launch_bounds__(kBlock) void path_kernel_persistent(DevScene sc, De
         } else if ((pick == 2 && phase == ST_LEAF) || (pick == 1 && (phase == ST_DESC || phase == ST_POP))) {
             bool finished = false;  // this lane has to pop (or the instance is done)
             if (pick == 2) {
-                // one triangle of `for i in first..=last`, hit.rs:111-121
-                float t = triangle_ray_intersect(it0, it1, it2, it3.x, lpos, ldir, kEps, t_hi, cull);
+                // one triangle of `for i in first..=last`, hit.rs:111-121.  The item is the triangle's
+                // DevTriTest: plane and range checks as in triangle_ray_intersect, then the three
+                // edge signs from the approximate edge functions; a lane whose signs are not
+                // clear-cut fetches the full triangle and runs the exact test.
+                float t;
+                bool unclear = false;
+                {
+                    const V3 normal = v3(it0.x, it0.y, it0.z);
+                    const float dot_prod = dot(normal, ldir);
+                    bool out = fabsf(dot_prod) < kEps || (cull && dot_prod > 0.0f);
+                    t = -(dot(normal, lpos) + it0.w) / dot_prod;
+                    out = out || t < kEps || t > t_hi;
+                    const V3 g = (lpos + ldir * t) - v3(it1.x, it1.y, it1.z);
+                    const float m0[3] = {it2.x, it2.y, it2.z}, m1[3] = {it3.x, it3.y, it3.z};
+                    const TriSigns sg = tri_filter_eval(m0, m1, it1.w, it2.w, it3.w, g.x, g.y, g.z);
+                    unclear = !out && tri_filter_unclear(sg);
+                    if (out || sg.s_min < 0.0f) t = RT_INF;
+                }
+                if (__ballot(unclear) != 0ull) {
+                    if (unclear) {
+                        const float4* fp = reinterpret_cast<const float4*>(&sc.tris[tri_i]);
+                        t = triangle_ray_intersect(fp[0], fp[1], fp[2], fp[3].x, lpos, ldir, kEps, t_hi, cull);
+                    }
+                }
                 if (!is_inf_bits(t)) {
                     t_hi = t;
                     rec.t = t;
@@ -360,7 +383,7 @@ __global__ __launch_bounds__(kBlock) void path_kernel_persistent(DevScene sc, De
                     finished = true;
                 } else {
                     tri_i += 1;
-                    next = reinterpret_cast<const float4*>(&sc.tris[tri_i]);
+                    next = reinterpret_cast<const float4*>(&sc.tri_tests[tri_i]);
                 }
             } else {
                 const bool desc = phase == ST_DESC;
@@ -441,7 +464,7 @@ __global__ __launch_bounds__(kBlock) void path_kernel_persistent(DevScene sc, De
                     phase = ST_LEAF;
                     tri_i = a;
                     tri_last = b;
-                    next = reinterpret_cast<const float4*>(&sc.tris[a]);
+                    next = reinterpret_cast<const float4*>(&sc.tri_tests[a]);
                 } else {
                     finished = true;  // `first..=last` with nothing in it
                 }

@@ -25,6 +25,7 @@ struct rt_ctx {
     bool have_scene = false;
     DevNode* d_nodes = nullptr;
     DevTri* d_tris = nullptr;
+    DevTriTest* d_tri_tests = nullptr;
     DevObject* d_objects = nullptr;
     DevInstance* d_instances = nullptr;
     std::vector<DevInstance> h_instances;
@@ -85,6 +86,7 @@ void free_dev(T*& p) {
 void free_scene(rt_ctx* c) {
     free_dev(c->d_nodes);
     free_dev(c->d_tris);
+    free_dev(c->d_tri_tests);
     free_dev(c->d_objects);
     free_dev(c->d_instances);
     c->have_scene = false;
@@ -176,7 +178,7 @@ int render(rt_ctx* c, const rt_cam_data& cam, uint32_t n_frames) {
     if (rc != RT_OK) return rc;
     if (n_frames == 0) return RT_OK;
 
-    DevScene sc{c->d_nodes, c->d_tris, c->d_objects, c->d_instances, c->n_instances, c->fast_div ? 1u : 0u};
+    DevScene sc{c->d_nodes, c->d_tris, c->d_tri_tests, c->d_objects, c->d_instances, c->n_instances, c->fast_div ? 1u : 0u};
     DevCam dc = make_cam(cam, c->frame_stride, c->seed_mode);
     DevRows rows;
     rows.strip_h = c->world > 1 ? c->strip_h : cam.canvas_height;
@@ -325,12 +327,16 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_info* info, const rt_vertex* verti
     const size_t n_tris = g.tris.empty() ? 1 : g.tris.size();
     RT_HIP(c, hipMalloc(&c->d_nodes, n_nodes * sizeof(DevNode)));
     RT_HIP(c, hipMalloc(&c->d_tris, n_tris * sizeof(DevTri)));
+    RT_HIP(c, hipMalloc(&c->d_tri_tests, n_tris * sizeof(DevTriTest)));
     RT_HIP(c, hipMalloc(&c->d_objects, g.objects.size() * sizeof(DevObject)));
     RT_HIP(c, hipMalloc(&c->d_instances, g.instances.size() * sizeof(DevInstance)));
     if (!g.nodes.empty())
         RT_HIP(c, hipMemcpy(c->d_nodes, g.nodes.data(), g.nodes.size() * sizeof(DevNode), hipMemcpyHostToDevice));
     if (!g.tris.empty())
         RT_HIP(c, hipMemcpy(c->d_tris, g.tris.data(), g.tris.size() * sizeof(DevTri), hipMemcpyHostToDevice));
+    if (!g.tri_tests.empty())
+        RT_HIP(c, hipMemcpy(c->d_tri_tests, g.tri_tests.data(), g.tri_tests.size() * sizeof(DevTriTest),
+                            hipMemcpyHostToDevice));
     RT_HIP(c, hipMemcpy(c->d_objects, g.objects.data(), g.objects.size() * sizeof(DevObject), hipMemcpyHostToDevice));
     RT_HIP(c, hipMemcpy(c->d_instances, g.instances.data(), g.instances.size() * sizeof(DevInstance),
                         hipMemcpyHostToDevice));

@@ -8,6 +8,7 @@
 #include "fastdiv.hpp"
 #include "host_math.hpp"
 #include "host_scene.hpp"
+#include "trifilter.hpp"
 
 using namespace rt;
 
@@ -299,6 +300,75 @@ uint64_t rt_selftest_slab_filter(uint64_t n, uint64_t seed, uint64_t* n_clear) {
         } else if (hit && ((dist > t_hi) != (t_near > t_hi))) {
             ++bad;
         }
+    }
+    if (n_clear) *n_clear = clear;
+    return bad;
+}
+
+uint64_t rt_selftest_tri_filter(uint64_t n, uint64_t seed, uint64_t* n_clear) {
+    auto next = [&seed]() {
+        seed += 0x9E3779B97F4A7C15ull;
+        uint64_t z = seed;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        return z ^ (z >> 31);
+    };
+    auto unit = [&next]() { return float(next() >> 40) * (1.0f / 16777216.0f); };  // [0, 1)
+    auto sym = [&unit]() { return unit() * 2.0f - 1.0f; };
+    auto nudge = [](float v, int ulps) {
+        for (int i = 0; i < (ulps < 0 ? -ulps : ulps); ++i) v = std::nextafter(v, ulps < 0 ? -INFINITY : INFINITY);
+        return v;
+    };
+    uint64_t bad = 0, clear = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        // a triangle of size `size` somewhere within `offset` of the origin
+        float size = std::ldexp(1.0f, int(next() % 24) - 12), offset = std::ldexp(1.0f, int(next() % 16) - 4);
+        V3 c = v3(sym() * offset, sym() * offset, sym() * offset);
+        V3 p[3];
+        for (int k = 0; k < 3; ++k) p[k] = c + v3(sym() * size, sym() * size, sym() * size);
+        if (next() % 16 == 0) p[2] = p[1] + (p[1] - p[0]) * unit();  // a sliver
+        // the plane as the scene upload computes it (hit.rs:145-148)
+        V3 normal = normalize(cross(p[1] - p[0], p[2] - p[0]));
+        float d = -(dot(normal, p[0]));
+        float pf[3][3], nf[3] = {normal.x, normal.y, normal.z};
+        for (int k = 0; k < 3; ++k) st(pf[k], p[k]);
+        DevTriTest rec;
+        tri_filter_build(pf[0], pf[1], pf[2], nf, d, rec);
+        // a point: on an edge, at a vertex, a few ulps off either, inside, outside, far away
+        int kind = int(next() % 8), k = int(next() % 3);
+        V3 a = p[k], b = p[(k + 1) % 3], h;
+        float s = unit();
+        switch (kind) {
+            case 0: h = a + (b - a) * s; break;
+            case 1: h = a; break;
+            case 2:
+            case 3: {
+                h = kind == 2 ? a + (b - a) * s : a;
+                h.x = nudge(h.x, int(next() % 9) - 4);
+                h.y = nudge(h.y, int(next() % 9) - 4);
+                h.z = nudge(h.z, int(next() % 9) - 4);
+                break;
+            }
+            case 4: {
+                float u = unit(), v = unit() * (1.0f - u);
+                h = p[0] + (p[1] - p[0]) * u + (p[2] - p[0]) * v;
+                break;
+            }
+            case 5: h = a + (b - a) * s + normal * (sym() * size); break;
+            case 6: h = c + v3(sym() * size, sym() * size, sym() * size) * 3.0f; break;
+            default: h = c + v3(sym(), sym(), sym()) * (offset * 8.0f); break;
+        }
+        // the exact signs, hit.rs:160-188
+        bool inside = true;
+        for (int e = 0; e < 3; ++e) {
+            V3 cr = cross(p[(e + 1) % 3] - p[e], h - p[e]);
+            if (dot(normal, cr) < 0.0f) inside = false;
+        }
+        V3 g = h - p[0];
+        TriSigns sg = tri_filter_eval(rec.m0, rec.m1, rec.c1, rec.margin_scale, rec.e_len, g.x, g.y, g.z);
+        if (tri_filter_unclear(sg)) continue;
+        ++clear;
+        if ((sg.s_min >= 0.0f) != inside) ++bad;
     }
     if (n_clear) *n_clear = clear;
     return bad;

@@ -320,3 +320,14 @@ def test_slab_shortcut_never_decides_differently_when_it_calls_a_case_clear():
         clear = C.c_uint64(0)
         assert lib.rt_selftest_slab_filter(2_000_000, seed, C.byref(clear)) == 0
         assert 400_000 < clear.value < 1_900_000
+
+
+def test_triangle_shortcut_never_decides_differently_when_it_calls_a_case_clear():
+    """Inside/outside of the plane hit point is first read off approximate edge functions; a
+    sign within the error margin of zero sends the test to the exact cross products of
+    hit.rs:160-188.  Points are drawn on edges, at vertices and a few ulps off them, where
+    the exact evaluation's own rounding decides the sign."""
+    for seed in (1, 0xC0FFEE):
+        clear = C.c_uint64(0)
+        assert lib.rt_selftest_tri_filter(2_000_000, seed, C.byref(clear)) == 0
+        assert 500_000 < clear.value < 1_900_000
