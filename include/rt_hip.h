@@ -133,6 +133,7 @@ typedef struct rt_sched_stats {
     uint64_t iterations[4];
     uint64_t lanes[4];
     uint64_t cycles[4];
+    uint64_t wait_cycles[4]; /* the part of `cycles` spent waiting for the step's prefetched item */
 } rt_sched_stats;
 int rt_get_sched_stats(rt_ctx* ctx, rt_sched_stats* out);
 int rt_reset_stats(rt_ctx* ctx);

@@ -146,7 +146,7 @@ class App:
     def sched_stats(self):
         s = L.SchedStats()
         self._check(self._lib.rt_get_sched_stats(self._ctx, C.byref(s)))
-        return {"iterations": list(s.iterations), "lanes": list(s.lanes), "cycles": list(s.cycles)}
+        return {"iterations": list(s.iterations), "lanes": list(s.lanes), "cycles": list(s.cycles), "wait_cycles": list(s.wait_cycles)}
 
     def reset_stats(self):
         self._check(self._lib.rt_reset_stats(self._ctx))

@@ -6,15 +6,18 @@
 // (shader/src/modules/hit.rs:57-60, 77, 90-91).  Here everything a traversal
 // step needs sits in ONE 64-byte, 64-byte-aligned record:
 //
-//   DevNode  one INTERNAL node = the boxes of both children plus what each
-//            child is, so a visit is four 16-byte loads from one line and the
-//            near/far decision (hit.rs:92-100) needs no further fetch.  Leaves
-//            have no record of their own: their triangle range lives in the
-//            parent's child slot.
-//   DevTri   one triangle = its three vertices (already gathered) plus the
-//            normalised plane normal and plane offset that hit.rs:145-148
-//            recomputes on every test.  The host computes them once with the
-//            same operation order, so the bits are identical.
+//   DevNode     one INTERNAL node = the boxes of both children plus what each
+//               child is, so a visit is four 16-byte loads from one line and the
+//               near/far decision (hit.rs:92-100) needs no further fetch.
+//               Leaves have no record of their own: their triangle range lives
+//               in the parent's child slot.  The two children are interleaved
+//               coordinate by coordinate, so that every step of the slab test
+//               handles both of them in one packed (2 x f32) instruction.
+//   DevTri      one triangle = its three vertices (already gathered) plus the
+//               normalised plane normal and plane offset that hit.rs:145-148
+//               recomputes on every test.  The host computes them once with the
+//               same operation order, so the bits are identical.
+//   DevTriTest  what the persistent kernel's triangle step reads instead.
 #pragma once
 
 #include <cstdint>
@@ -23,19 +26,19 @@ namespace rt {
 
 constexpr uint32_t kInternalTag = 0xFFFFFFFFu;
 
-// What a stack slot / child slot refers to.
-//   internal child: a = dense index of its DevNode, b = kInternalTag
-//   leaf child:     a = first triangle, b = last triangle (inclusive, global)
-struct alignas(32) DevChild {
-    float mn[3];
-    uint32_t a;
-    float mx[3];
-    uint32_t b;
-};
-
+// Child k of an internal node (k = 0: the reference's child_1):
+//   box  = [lox[k], loy[k], loz[k]] .. [hix[k], hiy[k], hiz[k]]
+//   internal child: a[k] = dense index of its DevNode, b[k] = kInternalTag
+//   leaf child:     a[k] = first triangle, b[k] = last triangle (inclusive, global);
+//                   an empty leaf is the canonical (1, 0)
+// A stack entry names a child slot: (node index << 1) | k.
 struct alignas(64) DevNode {
-    DevChild c[2];
+    float lox[2], hix[2];
+    float loy[2], hiy[2];
+    float loz[2], hiz[2];
+    uint32_t a[2], b[2];
 };
+static_assert(sizeof(DevNode) == 64, "one 64-byte line");
 
 struct alignas(64) DevTri {
     float p0[3]; float nx;
@@ -50,35 +53,40 @@ struct alignas(64) DevTri {
 struct alignas(64) DevTriTest {
     float n[3];  float d;             // plane, same bits as DevTri's
     float p0[3]; float c1;            // first vertex; constant of the second edge function
-    float m0[3]; float margin_scale;  // n x (p1 - p0); 2^-18 * e_len
-    float m1[3]; float e_len;         // n x (p2 - p1); bound on the 1-norm of the edges
+    // m0 = n x (p1 - p0) and m1 = n x (p2 - p1), interleaved component by component
+    // so that both edge functions are evaluated by packed (2 x f32) instructions
+    float m01x[2], m01y[2];
+    float m01z[2]; float margin_scale;  // 2^-18 * e_len
+    float e_len;                        // bound on the 1-norm of the edges
 };
+static_assert(sizeof(DevTriTest) == 64, "one 64-byte line");
 
+// The root of an object's BVH in the shape of a node: child 0 is the root,
+// child 1 a copy of it that is never visited.
 struct alignas(64) DevObject {
-    DevChild root;  // the object's root box and what the root is
-    DevChild unused;  // pads the record to the 64 bytes of a DevNode
+    DevNode root;
 };
 
-// Three 64-byte lines.  The first is all that "move the ray into this
-// instance's space" needs, so that step is an ordinary 64-byte item fetch; the
-// second starts with a copy of the object's root record, which is the 32-byte
-// item "start traversing this instance" fetches.
+// Four 64-byte lines.  The first is all that "move the ray into this
+// instance's space" needs and the second all that "start traversing it" needs,
+// so both steps are ordinary 64-byte item fetches.
 struct alignas(64) DevInstance {
     float inv[12];   // inverse transform: X, Y, Z, T  (object <- world)
     uint32_t cull;
     uint32_t pad0[3];
-    DevChild root;   // copy of the object's root record
+    DevNode root;    // copy of the object's root record
+    float fwd[12];   // transform:         X, Y, Z, T  (world <- object)
     uint32_t object_id;
     uint32_t mat_kind;
+    float ior;
+    uint32_t pad1;
+    float color[3];
     float specular;
     float specular_roughness;
-    float color[3];
     float roughness;
-    float fwd[12];   // transform:         X, Y, Z, T  (world <- object)
-    float ior;
-    uint32_t pad1[3];
+    uint32_t pad2[10];
 };
-static_assert(sizeof(DevInstance) == 192, "three 64-byte lines");
+static_assert(sizeof(DevInstance) == 256, "four 64-byte lines");
 
 struct DevCam {
     float X[3], Y[3], Z[3], T[3];  // camera-to-world
@@ -101,12 +109,16 @@ struct DevRows {
     uint32_t strip_h, rank, world, local_rows;
 };
 
+// Nodes, triangle test records and instances live in ONE allocation (the
+// arena), so that the persistent kernel can name any item by a 32-bit byte
+// offset from one base address.  tris and objects are separate.
 struct DevScene {
-    const DevNode* nodes;
+    const DevNode* nodes;          // = arena + node_off
     const DevTri* tris;
-    const DevTriTest* tri_tests;  // same numbering as tris
     const DevObject* objects;
-    const DevInstance* instances;
+    const DevInstance* instances;  // = arena + inst_off
+    const char* arena;
+    uint32_t node_off, tri_test_off, inst_off;  // byte offsets into the arena
     uint32_t n_instances;
     uint32_t fast_div;  // every box coordinate is 0 or has 2^-24 <= |b| <= 2^24 (see fastdiv.hpp)
 };
@@ -116,7 +128,7 @@ struct DevStats {
     // scheduling profile of the persistent kernel (only with counters on):
     // wave iterations that ran a control / box / triangle / instance set-up step,
     // the lanes that took part in them and the cycles they took
-    unsigned long long iters[4], lanes[4], cycles[4];
+    unsigned long long iters[4], lanes[4], cycles[4], wait_cycles[4];
 };
 
 // Work queues of the persistent kernel: 8 ranges of 64-pixel items (8x8 tiles),

@@ -44,13 +44,13 @@ constexpr float kDivHi = 16777216.0f;              // 2^24
 // true when v may be a divisor
 RT_HD bool div_den_ok(float d) {
     float ad = __builtin_fabsf(d);
-    return ad >= kDivLo && ad <= kDivHi;
+    return (int(ad >= kDivLo) & int(ad <= kDivHi)) != 0;
 }
 
 // true when v may be an operand of the subtraction that forms a numerator
 RT_HD bool div_term_ok(float v) {
     float av = __builtin_fabsf(v);
-    return v == 0.0f || (av >= kDivLo && av <= kDivHi);
+    return (int(v == 0.0f) | (int(av >= kDivLo) & int(av <= kDivHi))) != 0;
 }
 
 // a / d given r = RN(1/d), under the range conditions above.

@@ -48,30 +48,35 @@ void pack_affine(const rt_affine3a& m, float out[12]) {
     std::memcpy(out + 9, m.translation, 12);
 }
 
+// Fills child slot k of `out` from reference node `idx`.
 bool make_child(const rt_bvh* bvh, size_t n_bvh, size_t n_triangles, const std::vector<uint32_t>& dense, uint32_t idx,
-                DevChild& out, std::string& err) {
+                DevNode& out, int k, std::string& err) {
     if (idx >= n_bvh) {
         err = "BVH child index " + std::to_string(idx) + " out of range";
         return false;
     }
     const rt_bvh& n = bvh[idx];
-    std::memcpy(out.mn, n.bounding_box.min, 12);
-    std::memcpy(out.mx, n.bounding_box.max, 12);
+    out.lox[k] = n.bounding_box.min[0];
+    out.loy[k] = n.bounding_box.min[1];
+    out.loz[k] = n.bounding_box.min[2];
+    out.hix[k] = n.bounding_box.max[0];
+    out.hiy[k] = n.bounding_box.max[1];
+    out.hiz[k] = n.bounding_box.max[2];
     if (n.mode == RT_MODE_CHILDREN) {
-        out.a = dense[idx];
-        out.b = kInternalTag;
+        out.a[k] = dense[idx];
+        out.b[k] = kInternalTag;
     } else if (n.mode == RT_MODE_TRIANGLES) {
         uint32_t first = n.child_1_or_first_tri, last = n.child_2_or_last_tri;
         if (first == last + 1u) {  // `first..=last` with nothing in it
-            out.a = 1;
-            out.b = 0;
+            out.a[k] = 1;
+            out.b[k] = 0;
         } else if (first > last || last >= n_triangles) {
             err = "BVH node " + std::to_string(idx) + ": triangle range [" + std::to_string(first) + ", " +
                   std::to_string(last) + "] invalid for " + std::to_string(n_triangles) + " triangles";
             return false;
         } else {
-            out.a = first;
-            out.b = last;
+            out.a[k] = first;
+            out.b[k] = last;
         }
     } else {
         err = "BVH node " + std::to_string(idx) + ": unknown mode " + std::to_string(n.mode);
@@ -142,15 +147,16 @@ bool build_gpu_scene(const rt_scene_info& info, const rt_vertex* vertices, size_
     for (size_t i = 0; i < n_bvh; ++i) {
         if (bvh[i].mode != RT_MODE_CHILDREN) continue;
         DevNode& dn = out.nodes[dense[i]];
-        if (!make_child(bvh, n_bvh, n_triangles, dense, bvh[i].child_1_or_first_tri, dn.c[0], err)) return false;
-        if (!make_child(bvh, n_bvh, n_triangles, dense, bvh[i].child_2_or_last_tri, dn.c[1], err)) return false;
+        if (!make_child(bvh, n_bvh, n_triangles, dense, bvh[i].child_1_or_first_tri, dn, 0, err)) return false;
+        if (!make_child(bvh, n_bvh, n_triangles, dense, bvh[i].child_2_or_last_tri, dn, 1, err)) return false;
     }
 
     out.objects.resize(n_objects);
     std::memset(out.objects.data(), 0, n_objects * sizeof(DevObject));
     out.max_depth = 0;
     for (size_t i = 0; i < n_objects; ++i) {
-        if (!make_child(bvh, n_bvh, n_triangles, dense, objects[i].bvh_root, out.objects[i].root, err)) return false;
+        if (!make_child(bvh, n_bvh, n_triangles, dense, objects[i].bvh_root, out.objects[i].root, 0, err)) return false;
+        if (!make_child(bvh, n_bvh, n_triangles, dense, objects[i].bvh_root, out.objects[i].root, 1, err)) return false;
         uint32_t depth = bvh_depth(bvh, n_bvh, objects[i].bvh_root, kMaxBvhDepth);
         if (depth == 0) {
             err = "object " + std::to_string(i) + ": BVH is not a tree of at most " + std::to_string(kMaxBvhDepth) +

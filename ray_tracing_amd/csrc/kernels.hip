@@ -152,17 +152,22 @@ __global__ __launch_bounds__(kBlock) void path_kernel(DevScene sc, DevCam cam, D
 // Same per-lane work, in the same per-lane order, as path_kernel -- so the
 // results are identical -- but scheduled for 64-wide waves:
 //
-//  * Each lane is a small state machine that owns ONE pending item (a 64-byte
-//    internal node, a 64-byte triangle, or the 32-byte record of a popped child
-//    or of an object's root).  The load of the item is issued at the end of one step and
-//    consumed by the next, so a lane never has two dependent fetches in a step.
+//  * Each lane is a small state machine that owns ONE pending 64-byte item: an
+//    internal node (both children), a triangle test record, or the first or
+//    second line of an instance.  The load of the item is issued at the end of
+//    one step and consumed by the next, so a lane never has two dependent
+//    fetches in a step.  Items are named by 32-bit byte offsets into one arena.
 //  * A step is one of four kinds: CONTROL (generate a path, start a segment, or
 //    shade + accumulate after the last instance), SETUP (move the ray into the
 //    next instance's space), BOX (test the child box on top of the reference's
-//    stack, descend or pop) and LEAF (test one triangle).  Per iteration the wave runs only the kind
-//    most of its lanes are waiting for; the others keep their item and wait.
-//    No lane ever idles until its neighbours finish a leaf, a subtree, an
-//    instance, a bounce or a frame.
+//    stack, descend or pop) and LEAF (test one triangle).  Per iteration the
+//    wave runs only the kind most of its lanes are waiting for; the others keep
+//    their item and wait.  No lane ever idles until its neighbours finish a
+//    leaf, a subtree, an instance, a bounce or a frame.
+//  * The SETUP, BOX and LEAF steps are written without divergent branches: every
+//    lane computes, lanes that do not take part discard the results through
+//    selects.  The arithmetic of a BOX step covers both children of the node at
+//    once with packed 2 x f32 instructions.
 //  * Waves are persistent: a lane whose pixel has had all its frames pulls the
 //    next pixel from a work queue, so lanes never retire early.  There is one
 //    queue per XCD group (workgroups with equal blockIdx % 8 share an L2), each
@@ -171,6 +176,14 @@ __global__ __launch_bounds__(kBlock) void path_kernel(DevScene sc, DevCam cam, D
 // ---------------------------------------------------------------------------
 enum : uint32_t { ST_CONTROL = 0, ST_DESC = 1, ST_POP = 2, ST_LEAF = 3, ST_DEAD = 4, ST_SETUP = 5 };
 enum : uint32_t { CT_NEW_PIXEL = 0, CT_NEW_PATH = 1, CT_START_SEGMENT = 2, CT_NEXT_INSTANCE = 3 };
+constexpr uint32_t kNoItem = 0xFFFFFFFFu;
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f2 splat(float v) { return f2{v, v}; }
+__device__ __forceinline__ f2 vmin(f2 a, f2 b) { return __builtin_elementwise_min(a, b); }
+__device__ __forceinline__ f2 vmax(f2 a, f2 b) { return __builtin_elementwise_max(a, b); }
 
 template <int STACK_N, bool COUNT>
 __global__ __launch_bounds__(kBlock) void path_kernel_persistent(DevScene sc, DevCam cam, DevRows rows, DevFrame fr,
@@ -182,7 +195,8 @@ __global__ __launch_bounds__(kBlock) void path_kernel_persistent(DevScene sc, De
     const unsigned long long lanes_below = (1ull << lane) - 1ull;
 
     unsigned long long n_rays = 0, n_box = 0, n_internal = 0, n_tri = 0, n_paths = 0;
-    unsigned long long sched_iters[4] = {0, 0, 0, 0}, sched_lanes[4] = {0, 0, 0, 0}, sched_cycles[4] = {0, 0, 0, 0};  // wave-uniform
+    unsigned long long sched_iters[4] = {0, 0, 0, 0}, sched_lanes[4] = {0, 0, 0, 0}, sched_cycles[4] = {0, 0, 0, 0},
+                       sched_wait[4] = {0, 0, 0, 0};  // wave-uniform
 
     uint32_t phase = n_frames > 0 ? ST_CONTROL : ST_DEAD;
     uint32_t ctl = CT_NEW_PIXEL;
@@ -200,20 +214,21 @@ __global__ __launch_bounds__(kBlock) void path_kernel_persistent(DevScene sc, De
     Ray ray;
     ray.pos = v3(0.0f, 0.0f, 0.0f);
     ray.dir = v3(0.0f, 0.0f, 1.0f);
-    HitRecord rec;
+    HitRecord rec;  // rec.t doubles as the traversal's clamp: trace.rs:89 hands it to hit_bvh as t_max
     record_new(rec);
-    // traversal state of the current (segment, instance)
-    V3 lpos = ray.pos, ldir = ray.dir;
-    DirRcp rcp = make_dir_rcp(lpos, ldir, false);
-    float t_hi = RT_INF;
+    // traversal state of the current (segment, instance): the ray in object space as
+    // (direction, origin) pairs per axis, the reciprocals of the direction
+    f2 dpx = {0.0f, 0.0f}, dpy = {0.0f, 0.0f}, dpz = {1.0f, 0.0f};
+    float rcx = 1.0f, rcy = 1.0f, rcz = 1.0f;
+    bool rcp_ok = false;
     bool cull = false;
-    float4 it0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), it1 = it0, it2 = it0, it3 = it0;  // the pending item
-    uint32_t node = 0;  // ST_DESC: index of the node held in the item
-    uint32_t tri_i = 0, tri_last = 0, sp = 0;
-    bool sp_counted = false;  // ST_POP: the pending record came off the stack (its test is already counted)
+    f4 it0 = {0.0f, 0.0f, 0.0f, 0.0f}, it1 = it0, it2 = it0, it3 = it0;  // the pending item
+    uint32_t cur = 0;  // ST_DESC / ST_POP: (node index << 1) | child slot;  ST_LEAF: triangle index
+    uint32_t tri_last = 0, sp = 0;
+    bool sp_counted = false;  // ST_POP: the pending child came off the stack (its test is already counted)
 
     while (phase != ST_DEAD) {
-        const float4* next = nullptr;
+        uint32_t next_off = kNoItem;
         const unsigned long long t_begin = COUNT ? __builtin_readcyclecounter() : 0ull;
         // wave-uniform choice of the one kind of step this iteration runs
         const int w_ctl = __popcll(__ballot(phase == ST_CONTROL)) * q.w_ctl;
@@ -225,6 +240,10 @@ __global__ __launch_bounds__(kBlock) void path_kernel_persistent(DevScene sc, De
         if (w_setup > w_best) pick = 3, w_best = w_setup;
         if (w_ctl > w_best) pick = 0;
         if (COUNT) {
+            // profile only: how long the prefetched item still takes to arrive
+            const unsigned long long t0 = __builtin_readcyclecounter();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            sched_wait[pick] += __builtin_readcyclecounter() - t0;
             sched_iters[pick] += 1;
             sched_lanes[pick] += (unsigned)(pick == 0 ? w_ctl / q.w_ctl : pick == 1 ? w_box / q.w_box
                                             : pick == 2 ? w_leaf / q.w_leaf : w_setup / q.w_setup);
@@ -287,7 +306,7 @@ __global__ __launch_bounds__(kBlock) void path_kernel_persistent(DevScene sc, De
                         ctl = CT_NEXT_INSTANCE;
                     }
                     if (inst < sc.n_instances) {
-                        next = reinterpret_cast<const float4*>(&sc.instances[inst]);
+                        next_off = sc.inst_off + inst * (uint32_t)sizeof(DevInstance);
                         phase = ST_SETUP;
                         break;
                     }
@@ -331,170 +350,165 @@ __global__ __launch_bounds__(kBlock) void path_kernel_persistent(DevScene sc, De
                 }
             }
         } else if (pick == 3) {
-            if (phase == ST_SETUP) {
-                // trace.rs:76-94: the ray in the instance's object space, clamp (EPS, record.t).
-                // The item is the first line of the DevInstance: the inverse transform and the cull flag.
-                const float m[12] = {it0.x, it0.y, it0.z, it0.w, it1.x, it1.y, it1.z, it1.w, it2.x, it2.y, it2.z, it2.w};
-                lpos = xf_point(m, ray.pos);
-                ldir = xf_vector(m, ray.dir);
-                rcp = make_dir_rcp(lpos, ldir, sc.fast_div != 0u);
-                t_hi = rec.t;
-                cull = __float_as_uint(it3.x) != 0u;
-                next = reinterpret_cast<const float4*>(&sc.instances[inst].root);
-                sp = 0;
-                phase = ST_POP;
-                sp_counted = false;
-            }
-        } else if ((pick == 2 && phase == ST_LEAF) || (pick == 1 && (phase == ST_DESC || phase == ST_POP))) {
-            bool finished = false;  // this lane has to pop (or the instance is done)
+            // trace.rs:76-94: the ray in the instance's object space; the clamp (EPS, record.t) is
+            // rec.t itself.  The item is the first line of the DevInstance: the inverse transform
+            // and the cull flag.  The next item is its second line, the root in the shape of a node.
+            const bool act = phase == ST_SETUP;
+            const float m[12] = {it0.x, it0.y, it0.z, it0.w, it1.x, it1.y, it1.z, it1.w, it2.x, it2.y, it2.z, it2.w};
+            const V3 np = xf_point(m, ray.pos), nd = xf_vector(m, ray.dir);
+            const DirRcp nr = make_dir_rcp(np, nd, sc.fast_div != 0u);
+            dpx = act ? f2{nd.x, np.x} : dpx;
+            dpy = act ? f2{nd.y, np.y} : dpy;
+            dpz = act ? f2{nd.z, np.z} : dpz;
+            rcx = act ? nr.x : rcx;
+            rcy = act ? nr.y : rcy;
+            rcz = act ? nr.z : rcz;
+            rcp_ok = act ? nr.ok : rcp_ok;
+            cull = act ? __float_as_uint(it3.x) != 0u : cull;
+            sp = act ? 0u : sp;
+            cur = act ? 0u : cur;  // child slot 0 of the root record
+            sp_counted = act ? false : sp_counted;
+            phase = act ? (uint32_t)ST_POP : phase;
+            next_off = act ? sc.inst_off + inst * (uint32_t)sizeof(DevInstance) + 64u : next_off;
+        } else {
+            bool finished;  // this lane has to pop (or its instance is done)
+            const V3 lpos = v3(dpx.y, dpy.y, dpz.y), ldir = v3(dpx.x, dpy.x, dpz.x);
             if (pick == 2) {
                 // one triangle of `for i in first..=last`, hit.rs:111-121.  The item is the triangle's
                 // DevTriTest: plane and range checks as in triangle_ray_intersect, then the three
                 // edge signs from the approximate edge functions; a lane whose signs are not
                 // clear-cut fetches the full triangle and runs the exact test.
-                float t;
-                bool unclear = false;
-                {
-                    const V3 normal = v3(it0.x, it0.y, it0.z);
-                    const float dot_prod = dot(normal, ldir);
-                    bool out = fabsf(dot_prod) < kEps || (cull && dot_prod > 0.0f);
-                    t = -(dot(normal, lpos) + it0.w) / dot_prod;
-                    out = out || t < kEps || t > t_hi;
-                    const V3 g = (lpos + ldir * t) - v3(it1.x, it1.y, it1.z);
-                    const float m0[3] = {it2.x, it2.y, it2.z}, m1[3] = {it3.x, it3.y, it3.z};
-                    const TriSigns sg = tri_filter_eval(m0, m1, it1.w, it2.w, it3.w, g.x, g.y, g.z);
-                    unclear = !out && tri_filter_unclear(sg);
-                    if (out || sg.s_min < 0.0f) t = RT_INF;
-                }
+                const bool act = phase == ST_LEAF;
+                // (n . dir, n . pos) in one go: dot's order, (x + y) + z, in both halves
+                const f2 nd_np = (splat(it0.x) * dpx + splat(it0.y) * dpy) + splat(it0.z) * dpz;
+                const float dot_prod = nd_np.x;
+                bool out = fabsf(dot_prod) < kEps || (cull && dot_prod > 0.0f);
+                float t = -(nd_np.y + it0.w) / dot_prod;
+                out = out || t < kEps || t > rec.t;
+                const V3 g = (lpos + ldir * t) - v3(it1.x, it1.y, it1.z);
+                const f2 s01 = (it2.xy * splat(g.x) + it2.zw * splat(g.y)) + it3.xy * splat(g.z);
+                const TriSigns sg = tri_filter_signs(s01.x, s01.y, it1.w, it3.z, it3.w, g.x, g.y, g.z);
+                const bool unclear = act && !out && tri_filter_unclear(sg);
+                if (out || sg.s_min < 0.0f) t = RT_INF;
                 if (__ballot(unclear) != 0ull) {
                     if (unclear) {
-                        const float4* fp = reinterpret_cast<const float4*>(&sc.tris[tri_i]);
-                        t = triangle_ray_intersect(fp[0], fp[1], fp[2], fp[3].x, lpos, ldir, kEps, t_hi, cull);
+                        const float4* fp = reinterpret_cast<const float4*>(&sc.tris[cur]);
+                        t = triangle_ray_intersect(fp[0], fp[1], fp[2], fp[3].x, lpos, ldir, kEps, rec.t, cull);
                     }
                 }
-                if (!is_inf_bits(t)) {
-                    t_hi = t;
-                    rec.t = t;
-                    rec.triangle_id = tri_i;
-                    rec.instance_id = inst;
-                }
-                if (COUNT) rec.triangle_tests += 1;
-                if (tri_i == tri_last) {
-                    finished = true;
-                } else {
-                    tri_i += 1;
-                    next = reinterpret_cast<const float4*>(&sc.tri_tests[tri_i]);
-                }
+                const bool hit = act && !is_inf_bits(t);
+                rec.t = hit ? t : rec.t;
+                rec.triangle_id = hit ? cur : rec.triangle_id;
+                rec.instance_id = hit ? inst : rec.instance_id;
+                if (COUNT) rec.triangle_tests += act ? 1u : 0u;
+                const bool last = cur == tri_last;
+                finished = act && last;
+                const bool advance = act && !last;
+                cur = advance ? cur + 1u : cur;
+                next_off = advance ? sc.tri_test_off + cur * 64u : next_off;
             } else {
+                // The item is an internal node; both child boxes are tested at once.
+                //   ST_DESC: the node passed its own test (hit.rs:88-107).  The children are
+                //     ordered by centre distance; the nearer one is the node the reference pops
+                //     next.  The farther one it would test when popping it later: a ray that
+                //     misses that box altogether misses it whenever it is popped, so that outcome
+                //     is taken now and the entry is never pushed; a box that IS hit still waits on
+                //     the stack and is tested again at pop time against the clamp of that moment.
+                //   ST_POP: only child `cur & 1` is looked at: the node on top of the reference's
+                //     stack (hit.rs:77-86).
                 const bool desc = phase == ST_DESC;
-                float4 lo = it0, hi = it1;    // ST_POP: the item is the child record itself
-                float4 flo = it0, fhi = it1;  // ST_DESC: the farther child
-                uint32_t far_ref = 0;
-                if (desc) {
-                    // the item is an internal node that passed its test: hit.rs:88-107
-                    V3 c1 = (v3(it0.x, it0.y, it0.z) + v3(it1.x, it1.y, it1.z)) * 0.5f;
-                    V3 c2 = (v3(it2.x, it2.y, it2.z) + v3(it3.x, it3.y, it3.z)) * 0.5f;
-                    V3 e1 = c1 - lpos, e2 = c2 - lpos;
-                    bool first_is_1 = dot(e1, e1) < dot(e2, e2);
-                    lo = first_is_1 ? it0 : it2;
-                    hi = first_is_1 ? it1 : it3;
-                    flo = first_is_1 ? it2 : it0;
-                    fhi = first_is_1 ? it3 : it1;
-                    far_ref = (node << 1) | (first_is_1 ? 1u : 0u);  // the farther child's slot
-                    if (COUNT) {
-                        rec.internal_visits += 1;
-                        rec.box_tests += 1;  // the farther child, tested below
-                    }
+                const bool act = desc || phase == ST_POP;
+                const f2 lox = it0.xy, hix = it0.zw, loy = it1.xy, hiy = it1.zw, loz = it2.xy, hiz = it2.zw;
+                const uint32_t a0 = __float_as_uint(it3.x), a1 = __float_as_uint(it3.y);
+                const uint32_t b0 = __float_as_uint(it3.z), b1 = __float_as_uint(it3.w);
+                const f2 px = splat(lpos.x), py = splat(lpos.y), pz = splat(lpos.z);
+                // BoundingBox::center (shared/src/lib.rs:155-157) and hit.rs:92-100
+                const f2 ex = (lox + hix) * 0.5f - px, ey = (loy + hiy) * 0.5f - py, ez = (loz + hiz) * 0.5f - pz;
+                const f2 d2 = (ex * ex + ey * ey) + ez * ez;
+                const bool first_is_1 = d2.x < d2.y;
+                const bool near0 = desc ? first_is_1 : (cur & 1u) == 0u;  // the child tested "now" is child 0
+                if (COUNT) {
+                    rec.internal_visits += desc ? 1u : 0u;
+                    rec.box_tests += desc ? 2u : (act && !sp_counted) ? 1u : 0u;
                 }
-                // the node on top of the reference's stack: hit.rs:77-86
-                if (COUNT && !(phase == ST_POP && sp_counted)) rec.box_tests += 1;
                 // Three ways to the same decisions, chosen per wave.  The plain division is right
                 // for every lane; quotients through the cached reciprocal need the lane's operands
                 // in range; approximate quotients also need every comparison to be clear-cut.
                 // One lane outside a premise moves the whole wave to the next, dearer form.
-                float dist = RT_INF, far_dist = RT_INF;
+                float dist0 = RT_INF, dist1 = RT_INF;
                 bool decided = false;
-                const bool all_fast = __ballot(!rcp.ok) == 0ull;
+                const bool all_fast = __ballot(act && !rcp_ok) == 0ull;
                 if (all_fast) {
-                    SlabApprox sn = slab_approx(lo.x, lo.y, lo.z, hi.x, hi.y, hi.z, lpos.x, lpos.y, lpos.z, rcp.x, rcp.y, rcp.z);
-                    SlabApprox sf = slab_approx(flo.x, flo.y, flo.z, fhi.x, fhi.y, fhi.z, lpos.x, lpos.y, lpos.z, rcp.x, rcp.y, rcp.z);
-                    if (__ballot(slab_ambiguous(sn, t_hi) || (desc && slab_ambiguous(sf, t_hi))) == 0ull) {
-                        dist = slab_dist(sn);
-                        far_dist = slab_dist(sf);
+                    const f2 rx = splat(rcx), ry = splat(rcy), rz = splat(rcz);
+                    const f2 nx = (lox - px) * rx, ny = (loy - py) * ry, nz = (loz - pz) * rz;
+                    const f2 fx = (hix - px) * rx, fy = (hiy - py) * ry, fz = (hiz - pz) * rz;
+                    const f2 tn = vmax(vmax(vmin(nx, fx), vmin(ny, fy)), vmin(nz, fz));
+                    const f2 tf = vmin(vmin(vmax(nx, fx), vmax(ny, fy)), vmax(nz, fz));
+                    const SlabApprox s0 = {tn.x, tf.x}, s1 = {tn.y, tf.y};
+                    const bool amb0 = slab_ambiguous(s0, rec.t), amb1 = slab_ambiguous(s1, rec.t);
+                    const bool amb = act && (desc ? (amb0 || amb1) : (near0 ? amb0 : amb1));
+                    if (__ballot(amb) == 0ull) {
+                        dist0 = slab_dist(s0);
+                        dist1 = slab_dist(s1);
                         decided = true;
                     }
                 }
                 if (!decided) {
+                    const float4 lo0 = make_float4(lox.x, loy.x, loz.x, 0.0f), hi0 = make_float4(hix.x, hiy.x, hiz.x, 0.0f);
+                    const float4 lo1 = make_float4(lox.y, loy.y, loz.y, 0.0f), hi1 = make_float4(hix.y, hiy.y, hiz.y, 0.0f);
                     if (all_fast) {
-                        dist = hits_bounding_rcp(lpos, ldir, rcp, lo, hi);
-                        far_dist = hits_bounding_rcp(lpos, ldir, rcp, flo, fhi);
+                        DirRcp r;
+                        r.x = rcx;
+                        r.y = rcy;
+                        r.z = rcz;
+                        r.ok = true;
+                        dist0 = hits_bounding_rcp(lpos, ldir, r, lo0, hi0);
+                        dist1 = hits_bounding_rcp(lpos, ldir, r, lo1, hi1);
                     } else {
-                        dist = hits_bounding(lpos, ldir, lo, hi);
-                        far_dist = hits_bounding(lpos, ldir, flo, fhi);
+                        dist0 = hits_bounding(lpos, ldir, lo0, hi0);
+                        dist1 = hits_bounding(lpos, ldir, lo1, hi1);
                     }
                 }
-                // The reference tests the farther child when it pops it.  A ray that misses
-                // that box altogether misses it whenever it is popped, so that outcome is
-                // taken now and the entry is never pushed; a box that IS hit still waits on
-                // the stack and is tested again at pop time against the clamp of that moment.
+                const float near_dist = near0 ? dist0 : dist1, far_dist = near0 ? dist1 : dist0;
                 const bool far_alive = desc && far_dist != RT_INF;
-                bool alive = !culled(dist, t_hi);
-                if (phase == ST_DESC) {
-                    if (alive) {
-                        if (far_alive) {
-                            stack[sp * kBlock] = far_ref;
-                            sp += 1;
-                        }
-                    } else if (far_alive) {
-                        // the nearer child is out: the reference pops the farther one next,
-                        // with the clamp unchanged
-                        alive = !(far_dist > t_hi);
-                        lo = flo;
-                        hi = fhi;
-                    }
-                }
-                const uint32_t a = __float_as_uint(lo.w), b = __float_as_uint(hi.w);
-                if (!alive) {
-                    finished = true;
-                } else if (b == kInternalTag) {
-                    phase = ST_DESC;
-                    node = a;
-                    next = reinterpret_cast<const float4*>(&sc.nodes[a]);
-                } else if (a <= b) {
-                    phase = ST_LEAF;
-                    tri_i = a;
-                    tri_last = b;
-                    next = reinterpret_cast<const float4*>(&sc.tri_tests[a]);
-                } else {
-                    finished = true;  // `first..=last` with nothing in it
-                }
+                bool alive = !culled(near_dist, rec.t);
+                const bool push = alive && far_alive;
+                // the nearer child is out: the reference pops the farther one next, clamp unchanged
+                const bool take_far = !alive && far_alive;
+                alive = alive || (take_far && !(far_dist > rec.t));
+                if (push) stack[sp * kBlock] = (cur & ~1u) | (near0 ? 1u : 0u);  // the farther child's slot
+                sp += push ? 1u : 0u;
+                const bool chosen0 = near0 != take_far;
+                const uint32_t a = chosen0 ? a0 : a1, b = chosen0 ? b0 : b1;
+                const bool internal = act && alive && b == kInternalTag;
+                const bool leaf = act && alive && b != kInternalTag && a <= b;  // a > b: `first..=last` with nothing in it
+                finished = act && !internal && !leaf;
+                phase = internal ? (uint32_t)ST_DESC : leaf ? (uint32_t)ST_LEAF : phase;
+                cur = internal ? a << 1 : leaf ? a : cur;
+                tri_last = leaf ? b : tri_last;
+                next_off = internal ? sc.node_off + a * 64u : leaf ? sc.tri_test_off + a * 64u : next_off;
             }
-            if (finished) {
-                if (sp == 0) {
-                    inst += 1;  // this instance is done, trace.rs:76
-                    if (inst < sc.n_instances) {
-                        next = reinterpret_cast<const float4*>(&sc.instances[inst]);
-                        phase = ST_SETUP;
-                    } else {
-                        ctl = CT_NEXT_INSTANCE;  // shade
-                        phase = ST_CONTROL;
-                    }
-                } else {
-                    sp -= 1;
-                    uint32_t ref = stack[sp * kBlock];
-                    phase = ST_POP;
-                    sp_counted = true;
-                    next = reinterpret_cast<const float4*>(&sc.nodes[ref >> 1].c[ref & 1u]);
-                }
-            }
+            // a lane that is through with its node or leaf: pop, or this instance is done (trace.rs:76)
+            const bool pop = finished && sp != 0u;
+            const bool inst_end = finished && sp == 0u;
+            uint32_t ref = 0;
+            if (pop) ref = stack[(sp - 1u) * kBlock];
+            sp -= pop ? 1u : 0u;
+            sp_counted = pop ? true : sp_counted;
+            inst += inst_end ? 1u : 0u;
+            const bool more = inst < sc.n_instances;
+            phase = pop ? (uint32_t)ST_POP : inst_end ? (more ? (uint32_t)ST_SETUP : (uint32_t)ST_CONTROL) : phase;
+            cur = pop ? ref : cur;
+            ctl = inst_end ? (uint32_t)CT_NEXT_INSTANCE : ctl;  // shade, once every instance is done
+            next_off = pop ? sc.node_off + (ref >> 1) * 64u
+                           : (inst_end && more) ? sc.inst_off + inst * (uint32_t)sizeof(DevInstance) : next_off;
         }
-        if (next) {
-            it0 = next[0];
-            it1 = next[1];
-            if (phase != ST_POP) {  // a child record is 32 bytes, a node or a triangle 64
-                it2 = next[2];
-                it3 = next[3];
-            }
+        if (next_off != kNoItem) {
+            const f4* p = reinterpret_cast<const f4*>(sc.arena + next_off);
+            it0 = p[0];
+            it1 = p[1];
+            it2 = p[2];
+            it3 = p[3];
         }
         if (COUNT) sched_cycles[pick] += __builtin_readcyclecounter() - t_begin;
     }
@@ -504,6 +518,7 @@ __global__ __launch_bounds__(kBlock) void path_kernel_persistent(DevScene sc, De
             atomicAdd(&fr.stats->iters[k], sched_iters[k]);
             atomicAdd(&fr.stats->lanes[k], sched_lanes[k]);
             atomicAdd(&fr.stats->cycles[k], sched_cycles[k]);
+            atomicAdd(&fr.stats->wait_cycles[k], sched_wait[k]);
         }
     }
 }

@@ -23,11 +23,10 @@ struct rt_ctx {
 
     // scene, resident in HBM
     bool have_scene = false;
-    DevNode* d_nodes = nullptr;
+    char* d_arena = nullptr;  // nodes | triangle test records | instances
+    size_t node_off = 0, tri_test_off = 0, inst_off = 0, arena_bytes = 0;
     DevTri* d_tris = nullptr;
-    DevTriTest* d_tri_tests = nullptr;
     DevObject* d_objects = nullptr;
-    DevInstance* d_instances = nullptr;
     std::vector<DevInstance> h_instances;
     uint32_t n_instances = 0;
     uint32_t max_depth = 0;
@@ -84,11 +83,9 @@ void free_dev(T*& p) {
 }
 
 void free_scene(rt_ctx* c) {
-    free_dev(c->d_nodes);
+    free_dev(c->d_arena);
     free_dev(c->d_tris);
-    free_dev(c->d_tri_tests);
     free_dev(c->d_objects);
-    free_dev(c->d_instances);
     c->have_scene = false;
 }
 
@@ -178,7 +175,19 @@ int render(rt_ctx* c, const rt_cam_data& cam, uint32_t n_frames) {
     if (rc != RT_OK) return rc;
     if (n_frames == 0) return RT_OK;
 
-    DevScene sc{c->d_nodes, c->d_tris, c->d_tri_tests, c->d_objects, c->d_instances, c->n_instances, c->fast_div ? 1u : 0u};
+    DevScene sc;
+    sc.nodes = reinterpret_cast<const DevNode*>(c->d_arena + c->node_off);
+    sc.tris = c->d_tris;
+    sc.objects = c->d_objects;
+    sc.instances = reinterpret_cast<const DevInstance*>(c->d_arena + c->inst_off);
+    sc.arena = c->d_arena;
+    sc.node_off = (uint32_t)c->node_off;
+    sc.tri_test_off = (uint32_t)c->tri_test_off;
+    sc.inst_off = (uint32_t)c->inst_off;
+    sc.n_instances = c->n_instances;
+    sc.fast_div = c->fast_div ? 1u : 0u;
+    // the persistent kernel names items by 32-bit byte offsets into the arena
+    const bool offsets_fit = c->arena_bytes <= 0xFFFFFFFFull;
     DevCam dc = make_cam(cam, c->frame_stride, c->seed_mode);
     DevRows rows;
     rows.strip_h = c->world > 1 ? c->strip_h : cam.canvas_height;
@@ -200,7 +209,7 @@ int render(rt_ctx* c, const rt_cam_data& cam, uint32_t n_frames) {
     const uint32_t stack_needed = c->max_depth > 1 ? c->max_depth - 1 : 1;
 
     RT_HIP(c, hipEventRecord(c->ev0, c->stream));
-    if (c->pipeline == 0) {
+    if (c->pipeline == 0 || !offsets_fit) {
         RT_HIP(c, launch_path_kernel(sc, dc, rows, fr, n_frames, stack_needed, count, c->stream));
     } else {
         DevQueue q;
@@ -325,20 +334,23 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_info* info, const rt_vertex* verti
     // a scene whose only nodes are leaves still needs a valid pointer
     const size_t n_nodes = g.nodes.empty() ? 1 : g.nodes.size();
     const size_t n_tris = g.tris.empty() ? 1 : g.tris.size();
-    RT_HIP(c, hipMalloc(&c->d_nodes, n_nodes * sizeof(DevNode)));
+    c->node_off = 0;
+    c->tri_test_off = c->node_off + n_nodes * sizeof(DevNode);
+    c->inst_off = c->tri_test_off + n_tris * sizeof(DevTriTest);
+    c->arena_bytes = c->inst_off + g.instances.size() * sizeof(DevInstance);
+    RT_HIP(c, hipMalloc(&c->d_arena, c->arena_bytes));
     RT_HIP(c, hipMalloc(&c->d_tris, n_tris * sizeof(DevTri)));
-    RT_HIP(c, hipMalloc(&c->d_tri_tests, n_tris * sizeof(DevTriTest)));
     RT_HIP(c, hipMalloc(&c->d_objects, g.objects.size() * sizeof(DevObject)));
-    RT_HIP(c, hipMalloc(&c->d_instances, g.instances.size() * sizeof(DevInstance)));
     if (!g.nodes.empty())
-        RT_HIP(c, hipMemcpy(c->d_nodes, g.nodes.data(), g.nodes.size() * sizeof(DevNode), hipMemcpyHostToDevice));
+        RT_HIP(c, hipMemcpy(c->d_arena + c->node_off, g.nodes.data(), g.nodes.size() * sizeof(DevNode),
+                            hipMemcpyHostToDevice));
     if (!g.tris.empty())
         RT_HIP(c, hipMemcpy(c->d_tris, g.tris.data(), g.tris.size() * sizeof(DevTri), hipMemcpyHostToDevice));
     if (!g.tri_tests.empty())
-        RT_HIP(c, hipMemcpy(c->d_tri_tests, g.tri_tests.data(), g.tri_tests.size() * sizeof(DevTriTest),
+        RT_HIP(c, hipMemcpy(c->d_arena + c->tri_test_off, g.tri_tests.data(), g.tri_tests.size() * sizeof(DevTriTest),
                             hipMemcpyHostToDevice));
     RT_HIP(c, hipMemcpy(c->d_objects, g.objects.data(), g.objects.size() * sizeof(DevObject), hipMemcpyHostToDevice));
-    RT_HIP(c, hipMemcpy(c->d_instances, g.instances.data(), g.instances.size() * sizeof(DevInstance),
+    RT_HIP(c, hipMemcpy(c->d_arena + c->inst_off, g.instances.data(), g.instances.size() * sizeof(DevInstance),
                         hipMemcpyHostToDevice));
     c->h_instances = g.instances;
     c->n_instances = (uint32_t)g.instances.size();
@@ -365,7 +377,7 @@ int rt_set_materials(rt_ctx* c, const rt_material* materials, size_t n) {
     }
     RT_HIP(c, hipSetDevice(c->device));
     RT_HIP(c, hipStreamSynchronize(c->stream));
-    RT_HIP(c, hipMemcpy(c->d_instances, c->h_instances.data(), c->h_instances.size() * sizeof(DevInstance),
+    RT_HIP(c, hipMemcpy(c->d_arena + c->inst_off, c->h_instances.data(), c->h_instances.size() * sizeof(DevInstance),
                         hipMemcpyHostToDevice));
     return RT_OK;
 }
@@ -483,6 +495,7 @@ int rt_get_sched_stats(rt_ctx* c, rt_sched_stats* out) {
         out->iterations[k] = s.iters[k];
         out->lanes[k] = s.lanes[k];
         out->cycles[k] = s.cycles[k];
+        out->wait_cycles[k] = s.wait_cycles[k];
     }
     return RT_OK;
 }

@@ -365,7 +365,9 @@ uint64_t rt_selftest_tri_filter(uint64_t n, uint64_t seed, uint64_t* n_clear) {
             if (dot(normal, cr) < 0.0f) inside = false;
         }
         V3 g = h - p[0];
-        TriSigns sg = tri_filter_eval(rec.m0, rec.m1, rec.c1, rec.margin_scale, rec.e_len, g.x, g.y, g.z);
+        float s0 = (rec.m01x[0] * g.x + rec.m01y[0] * g.y) + rec.m01z[0] * g.z;
+        float s1 = (rec.m01x[1] * g.x + rec.m01y[1] * g.y) + rec.m01z[1] * g.z;
+        TriSigns sg = tri_filter_signs(s0, s1, rec.c1, rec.margin_scale, rec.e_len, g.x, g.y, g.z);
         if (tri_filter_unclear(sg)) continue;
         ++clear;
         if ((sg.s_min >= 0.0f) != inside) ++bad;

@@ -184,8 +184,9 @@ RT_DEV DirRcp make_dir_rcp(V3 pos, V3 dir, bool scene_ok) {
     r.x = 1.0f / dir.x;
     r.y = 1.0f / dir.y;
     r.z = 1.0f / dir.z;
-    r.ok = scene_ok && div_den_ok(dir.x) && div_den_ok(dir.y) && div_den_ok(dir.z) && div_term_ok(pos.x) &&
-           div_term_ok(pos.y) && div_term_ok(pos.z);
+    // bitwise on purpose: six cheap tests, no branches
+    r.ok = (int(scene_ok) & int(div_den_ok(dir.x)) & int(div_den_ok(dir.y)) & int(div_den_ok(dir.z)) &
+            int(div_term_ok(pos.x)) & int(div_term_ok(pos.y)) & int(div_term_ok(pos.z))) != 0;
     return r;
 }
 
@@ -241,21 +242,26 @@ RT_DEV bool culled(float dist, float t_hi) { return dist == RT_INF || dist > t_h
 // ---- Mesh::hit_bvh: hit.rs:65-123 ----------------------------------------------------
 // Same visit order, same tests, same counters as the reference's stack
 // machine.  What differs is where things are kept: a popped entry names a
-// child SLOT of an internal node (node*2 + slot), the slot carries that child's
-// box, so "pop, fetch node, test its box" is one 32-byte fetch; a node that
-// passes and is internal costs one 64-byte fetch that brings both child boxes
-// for the near/far rule; the nearer child is tested at once (the reference
-// would pop it next with nothing in between), the farther one waits on the
-// stack and is tested when popped, against the clamp of that moment.
+// child SLOT of an internal node (node*2 + slot), the node record carries both
+// children's boxes, so "pop, fetch node, test its box" is one 64-byte fetch; a
+// node that passes and is internal costs one 64-byte fetch that brings both
+// child boxes for the near/far rule; the nearer child is tested at once (the
+// reference would pop it next with nothing in between), the farther one waits
+// on the stack and is tested when popped, against the clamp of that moment.
 // `stack` points at this lane's column of an LDS array with `stride` entries
 // between levels.
+RT_DEV void load_child(const DevNode* n, uint32_t k, float4& lo, float4& hi) {
+    lo = make_float4(n->lox[k], n->loy[k], n->loz[k], __uint_as_float(n->a[k]));
+    hi = make_float4(n->hix[k], n->hiy[k], n->hiz[k], __uint_as_float(n->b[k]));
+}
+
 template <bool COUNT>
-RT_DEV void hit_bvh(const DevScene& sc, const DevChild* root, V3 pos, V3 dir, float t_lo, HitRecord& rec,
+RT_DEV void hit_bvh(const DevScene& sc, const DevNode* root, V3 pos, V3 dir, float t_lo, HitRecord& rec,
                     uint32_t instance_id, bool backface_cull, uint32_t* stack, uint32_t stride) {
     float t_hi = rec.t;
     uint32_t sp = 0;
-    const float4* rp = reinterpret_cast<const float4*>(root);
-    float4 lo = rp[0], hi = rp[1];
+    float4 lo, hi;
+    load_child(root, 0, lo, hi);
     if (COUNT) rec.box_tests += 1;
     bool alive = !culled(hits_bounding(pos, dir, lo, hi), t_hi);
     uint32_t a = __float_as_uint(lo.w), b = __float_as_uint(hi.w);
@@ -285,8 +291,10 @@ RT_DEV void hit_bvh(const DevScene& sc, const DevChild* root, V3 pos, V3 dir, fl
         }
         if (alive) {
             // internal node that passed its test (hit.rs:88-107)
-            const float4* np = reinterpret_cast<const float4*>(&sc.nodes[a]);
-            float4 lo1 = np[0], hi1 = np[1], lo2 = np[2], hi2 = np[3];
+            const DevNode* np = &sc.nodes[a];
+            float4 lo1, hi1, lo2, hi2;
+            load_child(np, 0, lo1, hi1);
+            load_child(np, 1, lo2, hi2);
             // BoundingBox::center (shared/src/lib.rs:155-157) and hit.rs:92-100
             V3 c1 = (v3(lo1.x, lo1.y, lo1.z) + v3(hi1.x, hi1.y, hi1.z)) * 0.5f;
             V3 c2 = (v3(lo2.x, lo2.y, lo2.z) + v3(hi2.x, hi2.y, hi2.z)) * 0.5f;
@@ -301,9 +309,7 @@ RT_DEV void hit_bvh(const DevScene& sc, const DevChild* root, V3 pos, V3 dir, fl
             if (sp == 0) break;
             sp -= 1;
             uint32_t ref = stack[sp * stride];
-            const float4* cp = reinterpret_cast<const float4*>(&sc.nodes[ref >> 1].c[ref & 1]);
-            lo = cp[0];
-            hi = cp[1];
+            load_child(&sc.nodes[ref >> 1], ref & 1u, lo, hi);
         }
         // the one place a box is tested: the node on top of the reference's stack
         if (COUNT) rec.box_tests += 1;

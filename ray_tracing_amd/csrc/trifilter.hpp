@@ -39,10 +39,10 @@ struct TriSigns {
 };
 
 // g = h - p0, evaluated as the reference evaluates it for its first edge.
-RT_HD TriSigns tri_filter_eval(const float m0[3], const float m1[3], float c1, float margin_scale, float e_len, float gx,
-                               float gy, float gz) {
-    float s0 = m0[0] * gx + m0[1] * gy + m0[2] * gz;
-    float s1 = (m1[0] * gx + m1[1] * gy + m1[2] * gz) + c1;
+// (s0, s1) = the two dot products m0 . g and m1 . g, however they were formed.
+RT_HD TriSigns tri_filter_signs(float s0, float s1_dot, float c1, float margin_scale, float e_len, float gx, float gy,
+                                float gz) {
+    float s1 = s1_dot + c1;
     float s2 = (c1 - s0) - s1;
     float G = (__builtin_fabsf(gx) + __builtin_fabsf(gy)) + __builtin_fabsf(gz);
     TriSigns r;
@@ -82,9 +82,13 @@ inline void tri_filter_build(const float p0[3], const float p1[3], const float p
     for (int k = 0; k < 3; ++k) {
         o.n[k] = n[k];
         o.p0[k] = p0[k];
-        o.m0[k] = float(m0[k]);
-        o.m1[k] = float(m1[k]);
     }
+    o.m01x[0] = float(m0[0]);
+    o.m01x[1] = float(m1[0]);
+    o.m01y[0] = float(m0[1]);
+    o.m01y[1] = float(m1[1]);
+    o.m01z[0] = float(m0[2]);
+    o.m01z[1] = float(m1[2]);
     o.d = d;
     o.c1 = float(c1);
     float Ef = ok ? std::nextafter(float(E), INFINITY) : INFINITY;

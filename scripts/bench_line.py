@@ -10,4 +10,6 @@ it, la, cy = s["iterations"], s["lanes"], s.get("cycles", [0] * len(s["iteration
 tot = max(1, sum(cy))
 print(sys.argv[1] if len(sys.argv) > 1 else "", round(d["value"]), "Mrays/s", round(r["kernel_ms"], 1), "ms",
       "iters(M)", [round(x / 1e6, 1) for x in it], "lanes/iter", [round(a / max(b, 1), 1) for a, b in zip(la, it)],
-      "cyc/iter", [round(a / max(b, 1)) for a, b in zip(cy, it)], "share", [round(x / tot, 3) for x in cy])
+      "cyc/iter", [round(a / max(b, 1)) for a, b in zip(cy, it)], "wait/iter",
+      [round(a / max(b, 1)) for a, b in zip(s.get("wait_cycles", [0] * len(it)), it)], "share",
+      [round(x / tot, 3) for x in cy])
