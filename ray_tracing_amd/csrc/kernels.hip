@@ -217,8 +217,8 @@ __global__ __launch_bounds__(kBlock) void path_kernel_persistent(DevScene sc, De
     HitRecord rec;  // rec.t doubles as the traversal's clamp: trace.rs:89 hands it to hit_bvh as t_max
     record_new(rec);
     // traversal state of the current (segment, instance): the ray in object space as
-    // (direction, origin) pairs per axis, the reciprocals of the direction
-    f2 dpx = {0.0f, 0.0f}, dpy = {0.0f, 0.0f}, dpz = {1.0f, 0.0f};
+    // (origin, direction) pairs per axis, the reciprocals of the direction
+    f2 dpx = {0.0f, 0.0f}, dpy = {0.0f, 0.0f}, dpz = {0.0f, 1.0f};
     float rcx = 1.0f, rcy = 1.0f, rcz = 1.0f;
     bool rcp_ok = false;
     bool cull = false;
@@ -357,9 +357,9 @@ __global__ __launch_bounds__(kBlock) void path_kernel_persistent(DevScene sc, De
             const float m[12] = {it0.x, it0.y, it0.z, it0.w, it1.x, it1.y, it1.z, it1.w, it2.x, it2.y, it2.z, it2.w};
             const V3 np = xf_point(m, ray.pos), nd = xf_vector(m, ray.dir);
             const DirRcp nr = make_dir_rcp(np, nd, sc.fast_div != 0u);
-            dpx = act ? f2{nd.x, np.x} : dpx;
-            dpy = act ? f2{nd.y, np.y} : dpy;
-            dpz = act ? f2{nd.z, np.z} : dpz;
+            dpx = act ? f2{np.x, nd.x} : dpx;
+            dpy = act ? f2{np.y, nd.y} : dpy;
+            dpz = act ? f2{np.z, nd.z} : dpz;
             rcx = act ? nr.x : rcx;
             rcy = act ? nr.y : rcy;
             rcz = act ? nr.z : rcz;
@@ -372,38 +372,38 @@ __global__ __launch_bounds__(kBlock) void path_kernel_persistent(DevScene sc, De
             next_off = act ? sc.inst_off + inst * (uint32_t)sizeof(DevInstance) + 64u : next_off;
         } else {
             bool finished;  // this lane has to pop (or its instance is done)
-            const V3 lpos = v3(dpx.y, dpy.y, dpz.y), ldir = v3(dpx.x, dpy.x, dpz.x);
+            const V3 lpos = v3(dpx.x, dpy.x, dpz.x), ldir = v3(dpx.y, dpy.y, dpz.y);
             if (pick == 2) {
                 // one triangle of `for i in first..=last`, hit.rs:111-121.  The item is the triangle's
                 // DevTriTest: plane and range checks as in triangle_ray_intersect, then the three
                 // edge signs from the approximate edge functions; a lane whose signs are not
                 // clear-cut fetches the full triangle and runs the exact test.
                 const bool act = phase == ST_LEAF;
-                // (n . dir, n . pos) in one go: dot's order, (x + y) + z, in both halves
-                const f2 nd_np = (splat(it0.x) * dpx + splat(it0.y) * dpy) + splat(it0.z) * dpz;
-                const float dot_prod = nd_np.x;
-                bool out = fabsf(dot_prod) < kEps || (cull && dot_prod > 0.0f);
-                float t = -(nd_np.y + it0.w) / dot_prod;
-                out = out || t < kEps || t > rec.t;
+                // (n . pos, n . dir) in one go: dot's order, (x + y) + z, in both halves
+                const f2 np_nd = (splat(it0.x) * dpx + splat(it0.y) * dpy) + splat(it0.z) * dpz;
+                const float dot_prod = np_nd.y;
+                bool out = (fabsf(dot_prod) < kEps) | (cull & (dot_prod > 0.0f));
+                float t = -(np_nd.x + it0.w) / dot_prod;
+                out = out | (t < kEps) | (t > rec.t);
                 const V3 g = (lpos + ldir * t) - v3(it1.x, it1.y, it1.z);
                 const f2 s01 = (it2.xy * splat(g.x) + it2.zw * splat(g.y)) + it3.xy * splat(g.z);
                 const TriSigns sg = tri_filter_signs(s01.x, s01.y, it1.w, it3.z, it3.w, g.x, g.y, g.z);
-                const bool unclear = act && !out && tri_filter_unclear(sg);
-                if (out || sg.s_min < 0.0f) t = RT_INF;
+                const bool unclear = act & !out & tri_filter_unclear(sg);
+                t = (out | (sg.s_min < 0.0f)) ? RT_INF : t;
                 if (__ballot(unclear) != 0ull) {
                     if (unclear) {
                         const float4* fp = reinterpret_cast<const float4*>(&sc.tris[cur]);
                         t = triangle_ray_intersect(fp[0], fp[1], fp[2], fp[3].x, lpos, ldir, kEps, rec.t, cull);
                     }
                 }
-                const bool hit = act && !is_inf_bits(t);
+                const bool hit = act & !is_inf_bits(t);
                 rec.t = hit ? t : rec.t;
                 rec.triangle_id = hit ? cur : rec.triangle_id;
                 rec.instance_id = hit ? inst : rec.instance_id;
                 if (COUNT) rec.triangle_tests += act ? 1u : 0u;
                 const bool last = cur == tri_last;
-                finished = act && last;
-                const bool advance = act && !last;
+                finished = act & last;
+                const bool advance = act & !last;
                 cur = advance ? cur + 1u : cur;
                 next_off = advance ? sc.tri_test_off + cur * 64u : next_off;
             } else {
@@ -417,43 +417,38 @@ __global__ __launch_bounds__(kBlock) void path_kernel_persistent(DevScene sc, De
                 //   ST_POP: only child `cur & 1` is looked at: the node on top of the reference's
                 //     stack (hit.rs:77-86).
                 const bool desc = phase == ST_DESC;
-                const bool act = desc || phase == ST_POP;
+                const bool act = desc | (phase == ST_POP);
                 const f2 lox = it0.xy, hix = it0.zw, loy = it1.xy, hiy = it1.zw, loz = it2.xy, hiz = it2.zw;
                 const uint32_t a0 = __float_as_uint(it3.x), a1 = __float_as_uint(it3.y);
                 const uint32_t b0 = __float_as_uint(it3.z), b1 = __float_as_uint(it3.w);
-                const f2 px = splat(lpos.x), py = splat(lpos.y), pz = splat(lpos.z);
+                const f2 px = dpx.xx, py = dpy.xx, pz = dpz.xx;
                 // BoundingBox::center (shared/src/lib.rs:155-157) and hit.rs:92-100
                 const f2 ex = (lox + hix) * 0.5f - px, ey = (loy + hiy) * 0.5f - py, ez = (loz + hiz) * 0.5f - pz;
                 const f2 d2 = (ex * ex + ey * ey) + ez * ez;
                 const bool first_is_1 = d2.x < d2.y;
-                const bool near0 = desc ? first_is_1 : (cur & 1u) == 0u;  // the child tested "now" is child 0
+                // the child tested "now" is child 0.  Bitwise on purpose, here and below: the step is
+                // meant to be one straight run of instructions, not a tree of branches.
+                const bool near0 = (desc & first_is_1) | (!desc & ((cur & 1u) == 0u));
                 if (COUNT) {
                     rec.internal_visits += desc ? 1u : 0u;
-                    rec.box_tests += desc ? 2u : (act && !sp_counted) ? 1u : 0u;
+                    rec.box_tests += desc ? 2u : (act & !sp_counted) ? 1u : 0u;
                 }
                 // Three ways to the same decisions, chosen per wave.  The plain division is right
                 // for every lane; quotients through the cached reciprocal need the lane's operands
                 // in range; approximate quotients also need every comparison to be clear-cut.
                 // One lane outside a premise moves the whole wave to the next, dearer form.
-                float dist0 = RT_INF, dist1 = RT_INF;
-                bool decided = false;
-                const bool all_fast = __ballot(act && !rcp_ok) == 0ull;
-                if (all_fast) {
-                    const f2 rx = splat(rcx), ry = splat(rcy), rz = splat(rcz);
-                    const f2 nx = (lox - px) * rx, ny = (loy - py) * ry, nz = (loz - pz) * rz;
-                    const f2 fx = (hix - px) * rx, fy = (hiy - py) * ry, fz = (hiz - pz) * rz;
-                    const f2 tn = vmax(vmax(vmin(nx, fx), vmin(ny, fy)), vmin(nz, fz));
-                    const f2 tf = vmin(vmin(vmax(nx, fx), vmax(ny, fy)), vmax(nz, fz));
-                    const SlabApprox s0 = {tn.x, tf.x}, s1 = {tn.y, tf.y};
-                    const bool amb0 = slab_ambiguous(s0, rec.t), amb1 = slab_ambiguous(s1, rec.t);
-                    const bool amb = act && (desc ? (amb0 || amb1) : (near0 ? amb0 : amb1));
-                    if (__ballot(amb) == 0ull) {
-                        dist0 = slab_dist(s0);
-                        dist1 = slab_dist(s1);
-                        decided = true;
-                    }
-                }
-                if (!decided) {
+                const f2 rx = splat(rcx), ry = splat(rcy), rz = splat(rcz);
+                const f2 nx = (lox - px) * rx, ny = (loy - py) * ry, nz = (loz - pz) * rz;
+                const f2 fx = (hix - px) * rx, fy = (hiy - py) * ry, fz = (hiz - pz) * rz;
+                const f2 tn = vmax(vmax(vmin(nx, fx), vmin(ny, fy)), vmin(nz, fz));
+                const f2 tf = vmin(vmin(vmax(nx, fx), vmax(ny, fy)), vmax(nz, fz));
+                const SlabApprox s0 = {tn.x, tf.x}, s1 = {tn.y, tf.y};
+                const bool amb0 = slab_ambiguous(s0, rec.t), amb1 = slab_ambiguous(s1, rec.t);
+                // a descent needs both children clear-cut, a pop only the child it looks at
+                const bool amb = act & (!rcp_ok | (amb0 & (desc | near0)) | (amb1 & (desc | !near0)));
+                float dist0 = slab_dist(s0), dist1 = slab_dist(s1);
+                if (__ballot(amb) != 0ull) {
+                    const bool all_fast = __ballot(act & !rcp_ok) == 0ull;
                     const float4 lo0 = make_float4(lox.x, loy.x, loz.x, 0.0f), hi0 = make_float4(hix.x, hiy.x, hiz.x, 0.0f);
                     const float4 lo1 = make_float4(lox.y, loy.y, loz.y, 0.0f), hi1 = make_float4(hix.y, hiy.y, hiz.y, 0.0f);
                     if (all_fast) {
@@ -470,27 +465,27 @@ __global__ __launch_bounds__(kBlock) void path_kernel_persistent(DevScene sc, De
                     }
                 }
                 const float near_dist = near0 ? dist0 : dist1, far_dist = near0 ? dist1 : dist0;
-                const bool far_alive = desc && far_dist != RT_INF;
-                bool alive = !culled(near_dist, rec.t);
-                const bool push = alive && far_alive;
+                const bool far_alive = desc & (far_dist != RT_INF);
+                bool alive = !((near_dist == RT_INF) | (near_dist > rec.t));
+                const bool push = alive & far_alive;
                 // the nearer child is out: the reference pops the farther one next, clamp unchanged
-                const bool take_far = !alive && far_alive;
-                alive = alive || (take_far && !(far_dist > rec.t));
+                const bool take_far = !alive & far_alive;
+                alive = alive | (take_far & !(far_dist > rec.t));
                 if (push) stack[sp * kBlock] = (cur & ~1u) | (near0 ? 1u : 0u);  // the farther child's slot
                 sp += push ? 1u : 0u;
                 const bool chosen0 = near0 != take_far;
                 const uint32_t a = chosen0 ? a0 : a1, b = chosen0 ? b0 : b1;
-                const bool internal = act && alive && b == kInternalTag;
-                const bool leaf = act && alive && b != kInternalTag && a <= b;  // a > b: `first..=last` with nothing in it
-                finished = act && !internal && !leaf;
+                const bool internal = act & alive & (b == kInternalTag);
+                const bool leaf = act & alive & (b != kInternalTag) & (a <= b);  // a > b: `first..=last` with nothing in it
+                finished = act & !internal & !leaf;
                 phase = internal ? (uint32_t)ST_DESC : leaf ? (uint32_t)ST_LEAF : phase;
                 cur = internal ? a << 1 : leaf ? a : cur;
                 tri_last = leaf ? b : tri_last;
                 next_off = internal ? sc.node_off + a * 64u : leaf ? sc.tri_test_off + a * 64u : next_off;
             }
             // a lane that is through with its node or leaf: pop, or this instance is done (trace.rs:76)
-            const bool pop = finished && sp != 0u;
-            const bool inst_end = finished && sp == 0u;
+            const bool pop = finished & (sp != 0u);
+            const bool inst_end = finished & (sp == 0u);
             uint32_t ref = 0;
             if (pop) ref = stack[(sp - 1u) * kBlock];
             sp -= pop ? 1u : 0u;
@@ -501,7 +496,7 @@ __global__ __launch_bounds__(kBlock) void path_kernel_persistent(DevScene sc, De
             cur = pop ? ref : cur;
             ctl = inst_end ? (uint32_t)CT_NEXT_INSTANCE : ctl;  // shade, once every instance is done
             next_off = pop ? sc.node_off + (ref >> 1) * 64u
-                           : (inst_end && more) ? sc.inst_off + inst * (uint32_t)sizeof(DevInstance) : next_off;
+                           : (inst_end & more) ? sc.inst_off + inst * (uint32_t)sizeof(DevInstance) : next_off;
         }
         if (next_off != kNoItem) {
             const f4* p = reinterpret_cast<const f4*>(sc.arena + next_off);

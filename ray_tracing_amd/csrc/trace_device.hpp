@@ -52,7 +52,7 @@ RT_DEV V3 ld3(const float* p) { return V3{p[0], p[1], p[2]}; }
 
 RT_DEV bool is_inf_bits(float v) {
     uint32_t b = __float_as_uint(v);
-    return b == 0x7F800000u || b == 0xFF800000u;
+    return (b & 0x7FFFFFFFu) == 0x7F800000u;
 }
 
 // ---- RNG: shader/src/modules/mod.rs:9-49 --------------------------------
