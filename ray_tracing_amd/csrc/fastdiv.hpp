@@ -103,13 +103,14 @@ RT_HD bool slab_ambiguous(SlabApprox s, float t_hi) {
     float an = __builtin_fabsf(s.t_near), af = __builtin_fabsf(s.t_far);
     bool clear_order = __builtin_fabsf(s.t_far - s.t_near) > kSlabMargin * (an + af);
     bool clear_clamp = __builtin_fabsf(s.t_near - t_hi) > kSlabMargin * an;
-    return !(clear_order & clear_clamp);
+    return !(clear_order && clear_clamp);
 }
 
 // The value hits_bounding would return, good for comparisons only: the entry
 // distance when the box is hit, +inf when it is not.
 RT_HD float slab_dist(SlabApprox s) {
-    return ((s.t_near < s.t_far) & (s.t_far > 0.0f)) ? s.t_near : __builtin_huge_valf();
+    bool ordered = s.t_near < s.t_far, ahead = s.t_far > 0.0f;
+    return (ordered && ahead) ? s.t_near : __builtin_huge_valf();
 }
 
 }  // namespace rt

@@ -382,28 +382,33 @@ __global__ __launch_bounds__(kBlock) void path_kernel_persistent(DevScene sc, De
                 // (n . pos, n . dir) in one go: dot's order, (x + y) + z, in both halves
                 const f2 np_nd = (splat(it0.x) * dpx + splat(it0.y) * dpy) + splat(it0.z) * dpz;
                 const float dot_prod = np_nd.y;
-                bool out = (fabsf(dot_prod) < kEps) | (cull & (dot_prod > 0.0f));
+                const bool grazing = fabsf(dot_prod) < kEps, back = dot_prod > 0.0f;
                 float t = -(np_nd.x + it0.w) / dot_prod;
-                out = out | (t < kEps) | (t > rec.t);
+                const bool before = t < kEps, beyond = t > rec.t;
+                const bool back_culled = cull && back;
+                const bool out = grazing || back_culled || before || beyond;
                 const V3 g = (lpos + ldir * t) - v3(it1.x, it1.y, it1.z);
                 const f2 s01 = (it2.xy * splat(g.x) + it2.zw * splat(g.y)) + it3.xy * splat(g.z);
                 const TriSigns sg = tri_filter_signs(s01.x, s01.y, it1.w, it3.z, it3.w, g.x, g.y, g.z);
-                const bool unclear = act & !out & tri_filter_unclear(sg);
-                t = (out | (sg.s_min < 0.0f)) ? RT_INF : t;
+                const bool vague = tri_filter_unclear(sg), outside = sg.s_min < 0.0f;
+                const bool unclear = act && !out && vague;
+                const bool miss = out || outside;
+                t = miss ? RT_INF : t;
                 if (__ballot(unclear) != 0ull) {
                     if (unclear) {
                         const float4* fp = reinterpret_cast<const float4*>(&sc.tris[cur]);
                         t = triangle_ray_intersect(fp[0], fp[1], fp[2], fp[3].x, lpos, ldir, kEps, rec.t, cull);
                     }
                 }
-                const bool hit = act & !is_inf_bits(t);
+                const bool finite = !is_inf_bits(t);
+                const bool hit = act && finite;
                 rec.t = hit ? t : rec.t;
                 rec.triangle_id = hit ? cur : rec.triangle_id;
                 rec.instance_id = hit ? inst : rec.instance_id;
                 if (COUNT) rec.triangle_tests += act ? 1u : 0u;
                 const bool last = cur == tri_last;
-                finished = act & last;
-                const bool advance = act & !last;
+                finished = act && last;
+                const bool advance = act && !last;
                 cur = advance ? cur + 1u : cur;
                 next_off = advance ? sc.tri_test_off + cur * 64u : next_off;
             } else {
@@ -417,7 +422,8 @@ __global__ __launch_bounds__(kBlock) void path_kernel_persistent(DevScene sc, De
                 //   ST_POP: only child `cur & 1` is looked at: the node on top of the reference's
                 //     stack (hit.rs:77-86).
                 const bool desc = phase == ST_DESC;
-                const bool act = desc | (phase == ST_POP);
+                const bool popping = phase == ST_POP;
+                const bool act = desc || popping;
                 const f2 lox = it0.xy, hix = it0.zw, loy = it1.xy, hiy = it1.zw, loz = it2.xy, hiz = it2.zw;
                 const uint32_t a0 = __float_as_uint(it3.x), a1 = __float_as_uint(it3.y);
                 const uint32_t b0 = __float_as_uint(it3.z), b1 = __float_as_uint(it3.w);
@@ -425,13 +431,21 @@ __global__ __launch_bounds__(kBlock) void path_kernel_persistent(DevScene sc, De
                 // BoundingBox::center (shared/src/lib.rs:155-157) and hit.rs:92-100
                 const f2 ex = (lox + hix) * 0.5f - px, ey = (loy + hiy) * 0.5f - py, ez = (loz + hiz) * 0.5f - pz;
                 const f2 d2 = (ex * ex + ey * ey) + ez * ez;
-                const bool first_is_1 = d2.x < d2.y;
-                // the child tested "now" is child 0.  Bitwise on purpose, here and below: the step is
-                // meant to be one straight run of instructions, not a tree of branches.
-                const bool near0 = (desc & first_is_1) | (!desc & ((cur & 1u) == 0u));
+                // Pinned here (an empty asm the compiler may not move): the ordering shares the
+                // splatted ray origin with the slab arithmetic below, and the splats only fold
+                // into the packed instructions' operand selectors within one basic block.
+                float d2_0 = d2.x, d2_1 = d2.y;
+                asm volatile("" : "+v"(d2_0), "+v"(d2_1));
+                const bool first_is_1 = d2_0 < d2_1;
+                // the child tested "now" is child 0.  Every condition of this step is computed into a
+                // named flag first and the flags are then combined: the step is meant to be one
+                // straight run of instructions, not a tree of branches.
+                const bool slot0 = (cur & 1u) == 0u;
+                const bool near0 = desc ? first_is_1 : slot0;
                 if (COUNT) {
+                    const bool first_test = act && !sp_counted;
                     rec.internal_visits += desc ? 1u : 0u;
-                    rec.box_tests += desc ? 2u : (act & !sp_counted) ? 1u : 0u;
+                    rec.box_tests += desc ? 2u : first_test ? 1u : 0u;
                 }
                 // Three ways to the same decisions, chosen per wave.  The plain division is right
                 // for every lane; quotients through the cached reciprocal need the lane's operands
@@ -445,10 +459,13 @@ __global__ __launch_bounds__(kBlock) void path_kernel_persistent(DevScene sc, De
                 const SlabApprox s0 = {tn.x, tf.x}, s1 = {tn.y, tf.y};
                 const bool amb0 = slab_ambiguous(s0, rec.t), amb1 = slab_ambiguous(s1, rec.t);
                 // a descent needs both children clear-cut, a pop only the child it looks at
-                const bool amb = act & (!rcp_ok | (amb0 & (desc | near0)) | (amb1 & (desc | !near0)));
+                const bool look0 = desc || near0, look1 = desc || !near0;
+                const bool unclear0 = amb0 && look0, unclear1 = amb1 && look1;
+                const bool amb = act && (!rcp_ok || unclear0 || unclear1);
                 float dist0 = slab_dist(s0), dist1 = slab_dist(s1);
                 if (__ballot(amb) != 0ull) {
-                    const bool all_fast = __ballot(act & !rcp_ok) == 0ull;
+                    const bool out_of_range = act && !rcp_ok;
+                    const bool all_fast = __ballot(out_of_range) == 0ull;
                     const float4 lo0 = make_float4(lox.x, loy.x, loz.x, 0.0f), hi0 = make_float4(hix.x, hiy.x, hiz.x, 0.0f);
                     const float4 lo1 = make_float4(lox.y, loy.y, loz.y, 0.0f), hi1 = make_float4(hix.y, hiy.y, hiz.y, 0.0f);
                     if (all_fast) {
@@ -465,38 +482,45 @@ __global__ __launch_bounds__(kBlock) void path_kernel_persistent(DevScene sc, De
                     }
                 }
                 const float near_dist = near0 ? dist0 : dist1, far_dist = near0 ? dist1 : dist0;
-                const bool far_alive = desc & (far_dist != RT_INF);
-                bool alive = !((near_dist == RT_INF) | (near_dist > rec.t));
-                const bool push = alive & far_alive;
+                const bool far_hit = far_dist != RT_INF, far_within = !(far_dist > rec.t);
+                const bool near_hit = near_dist != RT_INF, near_within = !(near_dist > rec.t);
+                const bool far_alive = desc && far_hit;
+                const bool near_alive = near_hit && near_within;
+                const bool push = near_alive && far_alive;
                 // the nearer child is out: the reference pops the farther one next, clamp unchanged
-                const bool take_far = !alive & far_alive;
-                alive = alive | (take_far & !(far_dist > rec.t));
+                const bool take_far = !near_alive && far_alive;
+                const bool far_taken = take_far && far_within;
+                const bool alive = near_alive || far_taken;
                 if (push) stack[sp * kBlock] = (cur & ~1u) | (near0 ? 1u : 0u);  // the farther child's slot
                 sp += push ? 1u : 0u;
                 const bool chosen0 = near0 != take_far;
                 const uint32_t a = chosen0 ? a0 : a1, b = chosen0 ? b0 : b1;
-                const bool internal = act & alive & (b == kInternalTag);
-                const bool leaf = act & alive & (b != kInternalTag) & (a <= b);  // a > b: `first..=last` with nothing in it
-                finished = act & !internal & !leaf;
+                const bool is_internal = b == kInternalTag, has_tris = a <= b;  // a > b: `first..=last` with nothing in it
+                const bool go = act && alive;
+                const bool internal = go && is_internal;
+                const bool leaf = go && !is_internal && has_tris;
+                finished = act && !internal && !leaf;
                 phase = internal ? (uint32_t)ST_DESC : leaf ? (uint32_t)ST_LEAF : phase;
                 cur = internal ? a << 1 : leaf ? a : cur;
                 tri_last = leaf ? b : tri_last;
                 next_off = internal ? sc.node_off + a * 64u : leaf ? sc.tri_test_off + a * 64u : next_off;
             }
             // a lane that is through with its node or leaf: pop, or this instance is done (trace.rs:76)
-            const bool pop = finished & (sp != 0u);
-            const bool inst_end = finished & (sp == 0u);
+            const bool empty = sp == 0u;
+            const bool pop = finished && !empty;
+            const bool inst_end = finished && empty;
             uint32_t ref = 0;
             if (pop) ref = stack[(sp - 1u) * kBlock];
             sp -= pop ? 1u : 0u;
             sp_counted = pop ? true : sp_counted;
             inst += inst_end ? 1u : 0u;
             const bool more = inst < sc.n_instances;
+            const bool to_setup = inst_end && more;
             phase = pop ? (uint32_t)ST_POP : inst_end ? (more ? (uint32_t)ST_SETUP : (uint32_t)ST_CONTROL) : phase;
             cur = pop ? ref : cur;
             ctl = inst_end ? (uint32_t)CT_NEXT_INSTANCE : ctl;  // shade, once every instance is done
             next_off = pop ? sc.node_off + (ref >> 1) * 64u
-                           : (inst_end & more) ? sc.inst_off + inst * (uint32_t)sizeof(DevInstance) : next_off;
+                           : to_setup ? sc.inst_off + inst * (uint32_t)sizeof(DevInstance) : next_off;
         }
         if (next_off != kNoItem) {
             const f4* p = reinterpret_cast<const f4*>(sc.arena + next_off);
