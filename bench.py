@@ -110,6 +110,7 @@ def main():
     ap.add_argument("--leaf-max", type=int, default=4,
                     help="largest leaf the BVH builder leaves unsplit (the reference's builder: 16, bvh.rs:75)")
     ap.add_argument("--pipeline", type=int, default=1, help="kernel: 0 plain nested loops, 1 persistent state machine")
+    ap.add_argument("--present", type=int, default=1, help="0: skip the gamma-corrected present image (accumulator only)")
     args = ap.parse_args()
 
     import torch
@@ -126,7 +127,8 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    from ray_tracing_amd import (App, RT_OPT_COUNTERS, RT_OPT_FRAME_STRIDE, RT_OPT_PIPELINE, RT_OPT_SEED_MODE)
+    from ray_tracing_amd import (App, RT_OPT_COUNTERS, RT_OPT_FRAME_STRIDE, RT_OPT_PIPELINE, RT_OPT_PRESENT,
+                                 RT_OPT_SEED_MODE)
     from ray_tracing_amd import _lib as L
     from ray_tracing_amd.distributed import reduce_samples, sample_split
 
@@ -138,6 +140,7 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     app = App.create(L.CamData.from_buffer_copy(cam0), scene, device=local_rank, stream=stream)
     app.set_option(RT_OPT_PIPELINE, args.pipeline)
+    app.set_option(RT_OPT_PRESENT, args.present)
     if partition == "tile":
         app.set_rows(STRIP_H, rank, world)
         first_frame, my_frames = 0, frames_per_step

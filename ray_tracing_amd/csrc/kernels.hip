@@ -204,7 +204,6 @@ __global__ __launch_bounds__(kBlock) void path_kernel_persistent(DevScene sc, De
     // pixel state
     uint32_t x = 0, y = 0, idx = 0;
     float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    float4 shown = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
     uint32_t frame = cam.frame;
     float fwm = cam.frames_without_move;
     uint32_t frames_left = 0;
@@ -332,17 +331,15 @@ __global__ __launch_bounds__(kBlock) void path_kernel_persistent(DevScene sc, De
                         continue;
                     }
                     if (state == STATE_RAY) color = v3(0.0f, 0.0f, 0.0f);  // never finished bouncing, trace.rs:204-205
-                    // shader/src/lib.rs:71-98, then the event loop's bookkeeping, main.rs:147-148
-                    float4 next_acc;
-                    accumulate(fwm, acc, color, next_acc, shown);
-                    acc = next_acc;
+                    // shader/src/lib.rs:71-98 (the presented colour is derived from the accumulator by
+                    // present_kernel afterwards), then the event loop's bookkeeping, main.rs:147-148
+                    acc = accumulate_only(fwm, acc, color);
                     n_paths += 1;
                     frame += cam.frame_stride;
                     fwm += 1.0f;
                     frames_left -= 1u;
                     if (frames_left == 0u) {
                         reinterpret_cast<float4*>(fr.acc)[idx] = acc;
-                        if (fr.present) reinterpret_cast<float4*>(fr.present)[idx] = gamma_correct(shown);
                         ctl = CT_NEW_PIXEL;
                         break;
                     }
@@ -542,6 +539,21 @@ __global__ __launch_bounds__(kBlock) void path_kernel_persistent(DevScene sc, De
     }
 }
 
+// The image the reference shows after a frame (lib.rs:85-108): the accumulator divided by
+// the sample count, gamma 1/2.2.  `fwm_last` is frames_without_move of the last frame
+// rendered into the accumulator.  Launched after the persistent kernel, which leaves the
+// presented image to this pass: the colour is a function of the stored accumulator alone.
+__global__ __launch_bounds__(kBlock) void present_kernel(DevCam cam, DevRows rows, DevFrame fr, float fwm_last) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= cam.W * rows.local_rows) return;
+    const uint32_t ly = i / cam.W, x = i - ly * cam.W;
+    const uint32_t y = global_row(rows, ly);
+    if (y >= cam.H) return;
+    const uint32_t idx = x + y * cam.W;
+    const float4 acc = reinterpret_cast<const float4*>(fr.acc)[idx];
+    reinterpret_cast<float4*>(fr.present)[idx] = gamma_correct(present_from_acc(fwm_last, acc));
+}
+
 hipError_t launch_path_kernel(const DevScene& sc, const DevCam& cam, const DevRows& rows, const DevFrame& fr,
                               uint32_t n_frames, uint32_t stack_needed, bool count, hipStream_t stream) {
     const uint32_t tiles_x = (cam.W + kTileW - 1) / kTileW;
@@ -584,6 +596,17 @@ hipError_t launch_persistent_kernel(const DevScene& sc, const DevCam& cam, const
         return hipErrorInvalidValue;
     }
 #undef RT_LAUNCH
+    hipError_t e2 = hipGetLastError();
+    if (e2 != hipSuccess || !fr.present) return e2;
+    const uint32_t n_pixels = cam.W * rows.local_rows;
+    // frames_without_move of the last frame, advanced the way the kernel advances it
+    float fwm_last = cam.frames_without_move;
+    for (uint32_t i = 1; i < n_frames; ++i) {
+        const float next = fwm_last + 1.0f;
+        if (next == fwm_last) break;  // the increments have stopped registering
+        fwm_last = next;
+    }
+    hipLaunchKernelGGL(present_kernel, dim3((n_pixels + kBlock - 1) / kBlock), block, 0, stream, cam, rows, fr, fwm_last);
     return hipGetLastError();
 }
 

@@ -516,6 +516,24 @@ RT_DEV void accumulate(float frames_without_move, float4 prev, V3 c, float4& acc
     present_out = new_color;
 }
 
+// The accumulator half of `accumulate`: what lib.rs:85-98 stores to binding 7.
+RT_DEV float4 accumulate_only(float frames_without_move, float4 prev, V3 c) {
+    bool nan = c.x > 1000.0f || c.y > 1000.0f || c.z > 1000.0f;
+    float4 rendered = make_float4(c.x, c.y, c.z, 1.0f);
+    if (frames_without_move < 0.5f) return rendered;
+    if (nan) return make_float4(0.0f, 1000000.0f, 0.0f, 1.0f);
+    return make_float4(prev.x + rendered.x, prev.y + rendered.y, prev.z + rendered.z, prev.w + rendered.w);
+}
+
+// The presented half: the colour lib.rs:85-98 derives from the value it has just
+// stored.  It is a function of that stored value and the frame's
+// frames_without_move alone, so it can be evaluated after the fact.
+RT_DEV float4 present_from_acc(float frames_without_move, float4 acc) {
+    if (frames_without_move < 0.5f) return acc;
+    float div = frames_without_move + 1.0f;
+    return make_float4(acc.x / div, acc.y / div, acc.z / div, acc.w / div);
+}
+
 RT_DEV float4 gamma_correct(float4 c) {
     const float g = 1.0f / 2.2f;
     return make_float4(powf(c.x, g), powf(c.y, g), powf(c.z, g), 1.0f);
