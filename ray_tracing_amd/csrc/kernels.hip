@@ -4,6 +4,7 @@
 #include "kernels.hpp"
 #include "trace_device.hpp"
 #include "trifilter.hpp"
+#include "wave_scan.hpp"
 
 namespace rt {
 
@@ -189,6 +190,7 @@ template <int STACK_N, bool COUNT>
 __global__ __launch_bounds__(kBlock) void path_kernel_persistent(DevScene sc, DevCam cam, DevRows rows, DevFrame fr,
                                                                  DevQueue q, uint32_t n_frames) {
     __shared__ uint32_t s_stack[STACK_N * kBlock];
+    __shared__ uint32_t s_tmp[kBlock];  // 64 words per wave: who works for whom in a LEAF step
 
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t* const stack = &s_stack[threadIdx.x];
@@ -226,7 +228,10 @@ __global__ __launch_bounds__(kBlock) void path_kernel_persistent(DevScene sc, De
     uint32_t tri_last = 0, sp = 0;
     bool sp_counted = false;  // ST_POP: the pending child came off the stack (its test is already counted)
 
-    while (phase != ST_DEAD) {
+    // Wave-uniform condition: lanes that have run out of pixels stay in the loop, inert, until
+    // the whole wave is done, so that the cross-lane operations of the LEAF step always see all
+    // 64 lanes.
+    while (__ballot(phase != ST_DEAD) != 0ull) {
         uint32_t next_off = kNoItem;
         const unsigned long long t_begin = COUNT ? __builtin_readcyclecounter() : 0ull;
         // wave-uniform choice of the one kind of step this iteration runs
@@ -371,43 +376,84 @@ __global__ __launch_bounds__(kBlock) void path_kernel_persistent(DevScene sc, De
             bool finished;  // this lane has to pop (or its instance is done)
             const V3 lpos = v3(dpx.x, dpy.x, dpz.x), ldir = v3(dpx.y, dpy.y, dpz.y);
             if (pick == 2) {
-                // one triangle of `for i in first..=last`, hit.rs:111-121.  The item is the triangle's
-                // DevTriTest: plane and range checks as in triangle_ray_intersect, then the three
-                // edge signs from the approximate edge functions; a lane whose signs are not
-                // clear-cut fetches the full triangle and runs the exact test.
-                const bool act = phase == ST_LEAF;
+                // `for i in first..=last`, hit.rs:111-121, for every lane that stands at a leaf --
+                // shared out over the whole wave.  The (lane, triangle) pairs of all those lanes
+                // ("owners") are numbered consecutively; worker lane w takes pair w: it borrows the
+                // owner's ray and clamp, fetches the triangle's DevTriTest and tests it (plane and
+                // range checks as in triangle_ray_intersect, then the three edge signs from the
+                // approximate edge functions; unclear signs -> the exact test on the full
+                // triangle).  Each owner then walks through its results in triangle order and keeps
+                // what the sequential loop would keep: a candidate survives when it is not beyond
+                // the best so far, so a later triangle at the same distance wins, as in hit.rs:115.
+                // One pass covers 64 pairs; what does not fit stays for the next LEAF step.
+                const bool owner = phase == ST_LEAF;
+                const uint32_t c = owner ? tri_last - cur + 1u : 0u;
+                const uint32_t incl = wave_incl_sum(c), excl = incl - c;
+                const uint32_t room = excl < 64u ? 64u - excl : 0u;
+                const uint32_t n_proc = c < room ? c : room;
+                // worker w -> owner: owners mark the first of their pairs, a running maximum spreads the mark
+                // (volatile: other lanes' stores must be seen, the compiler may not forward this lane's own)
+                volatile uint32_t* const tmp = &s_tmp[threadIdx.x & ~63u];
+                tmp[lane] = 0u;
+                if (n_proc != 0u) tmp[excl] = lane + 1u;
+                const uint32_t own1 = wave_incl_max(tmp[lane]);
+                const uint32_t o = own1 != 0u ? own1 - 1u : lane;
+                const uint32_t kw = lane - (uint32_t)__shfl((int)excl, (int)o, 64);
+                const bool work = own1 != 0u && kw < (uint32_t)__shfl((int)n_proc, (int)o, 64);
+                const uint32_t tri = (uint32_t)__shfl((int)cur, (int)o, 64) + kw;
+                f4 b0 = {0.0f, 0.0f, 0.0f, 0.0f}, b1 = b0, b2 = b0, b3 = b0;
+                if (work) {
+                    const f4* p = reinterpret_cast<const f4*>(sc.arena + (sc.tri_test_off + tri * 64u));
+                    b0 = p[0];
+                    b1 = p[1];
+                    b2 = p[2];
+                    b3 = p[3];
+                }
+                // the owner's ray, clamp and culling rule
+                const f2 wx = {__shfl(dpx.x, (int)o, 64), __shfl(dpx.y, (int)o, 64)};
+                const f2 wy = {__shfl(dpy.x, (int)o, 64), __shfl(dpy.y, (int)o, 64)};
+                const f2 wz = {__shfl(dpz.x, (int)o, 64), __shfl(dpz.y, (int)o, 64)};
+                const float w_hi = __shfl(rec.t, (int)o, 64);
+                const bool w_cull = __shfl(cull ? 1 : 0, (int)o, 64) != 0;
+                const V3 wpos = v3(wx.x, wy.x, wz.x), wdir = v3(wx.y, wy.y, wz.y);
                 // (n . pos, n . dir) in one go: dot's order, (x + y) + z, in both halves
-                const f2 np_nd = (splat(it0.x) * dpx + splat(it0.y) * dpy) + splat(it0.z) * dpz;
+                const f2 np_nd = (splat(b0.x) * wx + splat(b0.y) * wy) + splat(b0.z) * wz;
                 const float dot_prod = np_nd.y;
                 const bool grazing = fabsf(dot_prod) < kEps, back = dot_prod > 0.0f;
-                float t = -(np_nd.x + it0.w) / dot_prod;
-                const bool before = t < kEps, beyond = t > rec.t;
-                const bool back_culled = cull && back;
+                float t = -(np_nd.x + b0.w) / dot_prod;
+                const bool before = t < kEps, beyond = t > w_hi;
+                const bool back_culled = w_cull && back;
                 const bool out = grazing || back_culled || before || beyond;
-                const V3 g = (lpos + ldir * t) - v3(it1.x, it1.y, it1.z);
-                const f2 s01 = (it2.xy * splat(g.x) + it2.zw * splat(g.y)) + it3.xy * splat(g.z);
-                const TriSigns sg = tri_filter_signs(s01.x, s01.y, it1.w, it3.z, it3.w, g.x, g.y, g.z);
+                const V3 g = (wpos + wdir * t) - v3(b1.x, b1.y, b1.z);
+                const f2 s01 = (b2.xy * splat(g.x) + b2.zw * splat(g.y)) + b3.xy * splat(g.z);
+                const TriSigns sg = tri_filter_signs(s01.x, s01.y, b1.w, b3.z, b3.w, g.x, g.y, g.z);
                 const bool vague = tri_filter_unclear(sg), outside = sg.s_min < 0.0f;
-                const bool unclear = act && !out && vague;
-                const bool miss = out || outside;
+                const bool unclear = work && !out && vague;
+                const bool miss = !work || out || outside;
                 t = miss ? RT_INF : t;
                 if (__ballot(unclear) != 0ull) {
                     if (unclear) {
-                        const float4* fp = reinterpret_cast<const float4*>(&sc.tris[cur]);
-                        t = triangle_ray_intersect(fp[0], fp[1], fp[2], fp[3].x, lpos, ldir, kEps, rec.t, cull);
+                        const float4* fp = reinterpret_cast<const float4*>(&sc.tris[tri]);
+                        t = triangle_ray_intersect(fp[0], fp[1], fp[2], fp[3].x, wpos, wdir, kEps, w_hi, w_cull);
                     }
                 }
-                const bool finite = !is_inf_bits(t);
-                const bool hit = act && finite;
-                rec.t = hit ? t : rec.t;
-                rec.triangle_id = hit ? cur : rec.triangle_id;
+                // every owner goes through its own results in order
+                float best = rec.t;
+                uint32_t best_k = 0xFFFFFFFFu;
+                for (uint32_t kk = 0; __ballot(kk < n_proc) != 0ull; ++kk) {
+                    const float tk = __shfl(t, (int)((excl + kk) & 63u), 64);
+                    const bool mine = kk < n_proc, finite = !is_inf_bits(tk), farther = tk > best;
+                    const bool keep = mine && finite && !farther;
+                    best = keep ? tk : best;
+                    best_k = keep ? kk : best_k;
+                }
+                const bool hit = best_k != 0xFFFFFFFFu;
+                rec.t = hit ? best : rec.t;
+                rec.triangle_id = hit ? cur + best_k : rec.triangle_id;
                 rec.instance_id = hit ? inst : rec.instance_id;
-                if (COUNT) rec.triangle_tests += act ? 1u : 0u;
-                const bool last = cur == tri_last;
-                finished = act && last;
-                const bool advance = act && !last;
-                cur = advance ? cur + 1u : cur;
-                next_off = advance ? sc.tri_test_off + cur * 64u : next_off;
+                if (COUNT) rec.triangle_tests += n_proc;
+                cur += n_proc;
+                finished = owner && cur == tri_last + 1u;
             } else {
                 // The item is an internal node; both child boxes are tested at once.
                 //   ST_DESC: the node passed its own test (hit.rs:88-107).  The children are
@@ -500,7 +546,7 @@ __global__ __launch_bounds__(kBlock) void path_kernel_persistent(DevScene sc, De
                 phase = internal ? (uint32_t)ST_DESC : leaf ? (uint32_t)ST_LEAF : phase;
                 cur = internal ? a << 1 : leaf ? a : cur;
                 tri_last = leaf ? b : tri_last;
-                next_off = internal ? sc.node_off + a * 64u : leaf ? sc.tri_test_off + a * 64u : next_off;
+                next_off = internal ? sc.node_off + a * 64u : next_off;  // a leaf's triangles are fetched by the LEAF step
             }
             // a lane that is through with its node or leaf: pop, or this instance is done (trace.rs:76)
             const bool empty = sp == 0u;
