@@ -398,8 +398,11 @@ __global__ __launch_bounds__(kBlock) void path_kernel_persistent(DevScene sc, De
                 if (n_proc != 0u) tmp[excl] = lane + 1u;
                 const uint32_t own1 = wave_incl_max(tmp[lane]);
                 const uint32_t o = own1 != 0u ? own1 - 1u : lane;
-                const uint32_t kw = lane - (uint32_t)__shfl((int)excl, (int)o, 64);
-                const bool work = own1 != 0u && kw < (uint32_t)__shfl((int)n_proc, (int)o, 64);
+                // the owner's first pair, pair count and culling rule travel in one word
+                const uint32_t o_info = (uint32_t)__shfl((int)(excl | (n_proc << 8) | (cull ? 1u << 16 : 0u)), (int)o, 64);
+                const uint32_t kw = lane - (o_info & 0xFFu);
+                const bool has_owner = own1 != 0u, in_range = kw < ((o_info >> 8) & 0xFFu);
+                const bool work = has_owner && in_range;
                 const uint32_t tri = (uint32_t)__shfl((int)cur, (int)o, 64) + kw;
                 f4 b0 = {0.0f, 0.0f, 0.0f, 0.0f}, b1 = b0, b2 = b0, b3 = b0;
                 if (work) {
@@ -414,7 +417,7 @@ __global__ __launch_bounds__(kBlock) void path_kernel_persistent(DevScene sc, De
                 const f2 wy = {__shfl(dpy.x, (int)o, 64), __shfl(dpy.y, (int)o, 64)};
                 const f2 wz = {__shfl(dpz.x, (int)o, 64), __shfl(dpz.y, (int)o, 64)};
                 const float w_hi = __shfl(rec.t, (int)o, 64);
-                const bool w_cull = __shfl(cull ? 1 : 0, (int)o, 64) != 0;
+                const bool w_cull = (o_info & (1u << 16)) != 0u;
                 const V3 wpos = v3(wx.x, wy.x, wz.x), wdir = v3(wx.y, wy.y, wz.y);
                 // (n . pos, n . dir) in one go: dot's order, (x + y) + z, in both halves
                 const f2 np_nd = (splat(b0.x) * wx + splat(b0.y) * wy) + splat(b0.z) * wz;
@@ -440,12 +443,17 @@ __global__ __launch_bounds__(kBlock) void path_kernel_persistent(DevScene sc, De
                 // every owner goes through its own results in order
                 float best = rec.t;
                 uint32_t best_k = 0xFFFFFFFFu;
-                for (uint32_t kk = 0; __ballot(kk < n_proc) != 0ull; ++kk) {
-                    const float tk = __shfl(t, (int)((excl + kk) & 63u), 64);
-                    const bool mine = kk < n_proc, finite = !is_inf_bits(tk), farther = tk > best;
-                    const bool keep = mine && finite && !farther;
-                    best = keep ? tk : best;
-                    best_k = keep ? kk : best_k;
+                for (uint32_t k0 = 0; __ballot(k0 < n_proc) != 0ull; k0 += 4u) {
+                    float tk[4];  // four results on their way at a time
+#pragma unroll
+                    for (uint32_t j = 0; j < 4u; ++j) tk[j] = __shfl(t, (int)((excl + k0 + j) & 63u), 64);
+#pragma unroll
+                    for (uint32_t j = 0; j < 4u; ++j) {
+                        const bool mine = k0 + j < n_proc, finite = !is_inf_bits(tk[j]), farther = tk[j] > best;
+                        const bool keep = mine && finite && !farther;
+                        best = keep ? tk[j] : best;
+                        best_k = keep ? k0 + j : best_k;
+                    }
                 }
                 const bool hit = best_k != 0xFFFFFFFFu;
                 rec.t = hit ? best : rec.t;
