@@ -154,21 +154,25 @@ __global__ __launch_bounds__(kBlock) void path_kernel(DevScene sc, DevCam cam, D
 // results are identical -- but scheduled for 64-wide waves:
 //
 //  * Each lane is a small state machine that owns ONE pending 64-byte item: an
-//    internal node (both children), a triangle test record, or the first or
-//    second line of an instance.  The load of the item is issued at the end of
-//    one step and consumed by the next, so a lane never has two dependent
-//    fetches in a step.  Items are named by 32-bit byte offsets into one arena.
+//    internal node (both children) or the first or second line of an instance.
+//    The load of the item is issued at the end of one step and consumed by the
+//    next, so a lane never has two dependent fetches in a step.  Items are
+//    named by 32-bit byte offsets into one arena.
 //  * A step is one of four kinds: CONTROL (generate a path, start a segment, or
 //    shade + accumulate after the last instance), SETUP (move the ray into the
 //    next instance's space), BOX (test the child box on top of the reference's
-//    stack, descend or pop) and LEAF (test one triangle).  Per iteration the
-//    wave runs only the kind most of its lanes are waiting for; the others keep
-//    their item and wait.  No lane ever idles until its neighbours finish a
-//    leaf, a subtree, an instance, a bounce or a frame.
+//    stack, descend or pop) and LEAF (test the triangles of a leaf).  Per
+//    iteration the wave runs only the kind most of its lanes are waiting for;
+//    the others keep their item and wait.  No lane ever idles until its
+//    neighbours finish a subtree, an instance, a bounce or a frame.
 //  * The SETUP, BOX and LEAF steps are written without divergent branches: every
 //    lane computes, lanes that do not take part discard the results through
 //    selects.  The arithmetic of a BOX step covers both children of the node at
 //    once with packed 2 x f32 instructions.
+//  * A LEAF step is a job of the whole wave: the triangles of all lanes that
+//    stand at a leaf are dealt out over the 64 lanes, tested in parallel, and
+//    each owner then picks from its results what the sequential loop of
+//    hit.rs:111-121 would have kept.
 //  * Waves are persistent: a lane whose pixel has had all its frames pulls the
 //    next pixel from a work queue, so lanes never retire early.  There is one
 //    queue per XCD group (workgroups with equal blockIdx % 8 share an L2), each

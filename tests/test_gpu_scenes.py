@@ -162,6 +162,23 @@ def test_deep_tree_uses_the_large_stack():
         check_against_oracle(scene, ortho_like_cam(160, 32, z=7.0, fov=90.0), frames=2, pipeline=pipeline)
 
 
+def test_leaves_with_more_triangles_than_a_wave_has_lanes():
+    """The persistent kernel shares a leaf's triangles out over the 64 lanes of a wave, 64
+    (lane, triangle) pairs per pass.  A single 320-triangle leaf needs five passes per visit; two
+    leaves of 313 and 7 triangles leave lanes with unequal remainders between passes."""
+    verts, faces = S.icosphere(2)
+    verts = np.asarray(verts, F) * F(1.5)
+    faces = np.asarray(faces, np.uint32)
+    assert len(faces) == 320
+    lo, hi = (-1.6, -1.6, -1.6), (1.6, 1.6, 1.6)
+    one_leaf = make_manual_scene(verts, faces, [(lo, hi, 0, 319, 1)])
+    two_leaves = make_manual_scene(verts, faces, [(lo, hi, 1, 2, 0), (lo, hi, 0, 312, 1), (lo, hi, 313, 319, 1)])
+    for scene in (one_leaf, two_leaves):
+        for pipeline in (0, 1):
+            g, ref = check_against_oracle(scene, ortho_like_cam(96, 64, z=5.0), frames=2, pipeline=pipeline)
+        assert (ref.hit_triangle != 0xFFFFFFFF).mean() > 0.1
+
+
 def parse_obj(name):
     data = S._resource(name).encode()
     lib = L.load()
