@@ -51,6 +51,9 @@ if "SQ_THREAD_CYCLES_VALU" in pmc:
     d["valu_lane_utilisation"] = pmc["SQ_THREAD_CYCLES_VALU"] / (64 * pmc["SQ_ACTIVE_INST_VALU"])
     d["wave_time_waiting_on_memory"] = pmc["SQ_WAIT_ANY"] / pmc["SQ_WAVE_CYCLES"]
     d["wave_time_issuing_valu"] = pmc["SQ_ACTIVE_INST_VALU"] / pmc["SQ_WAVE_CYCLES"]
+if "SQ_ACTIVE_INST_VALU" in pmc and "GRBM_GUI_ACTIVE" in pmc:
+    # a wave64 VALU instruction occupies its SIMD for 4 cycles; 256 CUs x 4 SIMDs; GRBM_GUI_ACTIVE sums 8 XCDs
+    d["valu_pipe_busy"] = pmc["SQ_ACTIVE_INST_VALU"] * 4.0 / 1024.0 / (pmc["GRBM_GUI_ACTIVE"] / 8.0)
 if "TCC_EA0_RDREQ_sum" in pmc:
     n32, n128 = pmc.get("TCC_EA0_RDREQ_32B_sum", 0), pmc.get("TCC_EA0_RDREQ_128B_sum", 0)
     n64 = pmc["TCC_EA0_RDREQ_sum"] - n32 - n128
@@ -83,6 +86,7 @@ if "bench_line_under_trace" in out and "l2_fabric_read_bytes" in d:
                "method": "TCC_EA0_RDREQ (32B/64B/128B split) and TCC_EA0_WRREQ (64B split) per dispatch of the "
                          "persistent kernel, separate rocprofv3 --pmc passes; equals 2 x FETCH_SIZE + WRITE_SIZE, "
                          "the gfx950 correction for 128-byte read requests tallied at 64 bytes",
+               "valu_pipe_busy": d.get("valu_pipe_busy"),
                "source": f"profiles/{tag}_summary.json"}
     json.dump(traffic, open(os.path.join("profiles", "traffic_bench.json"), "w"), indent=1)
 path = os.path.join("profiles", f"{tag}_summary.json")
