@@ -8,10 +8,14 @@ Default workload = BASELINE.json configs[2], the one the Mrays/s metric and its
 1920x1080, 16 accumulated one-sample frames per step, depth 10, scene resident
 in HBM before the timed region.  With N > 1 (launched by torch.distributed.run,
 one process per GPU) the canvas is dealt to the ranks in interleaved 8-row
-strips; there is no collective in the data path, so the job is the same fixed
-image whatever N is ("strong" scaling).  A ray is one trace_ray invocation
-(shader/src/modules/trace.rs:195), primary and secondary alike; the count comes
-from the device's own counter.
+strips; there is no collective in the data path.  By default the canvas grows
+with N at a fixed aspect ratio (area x N: the same view, sampled more densely),
+so every GPU keeps one 1080p's worth of pixels: "weak" scaling.  `--scaling
+strong` keeps the 1920x1080 canvas for every N instead; that 25 ms job is
+bounded below by its longest pixel (16 dependent frames of up to 10 segments,
+about 10 ms of strictly serial steps), not by throughput.  A ray is one
+trace_ray invocation (shader/src/modules/trace.rs:195), primary and secondary
+alike; the count comes from the device's own counter.
 
 Other configs of BASELINE.json, for reference numbers (not the driver's bench
 line): c2 (10k tessellated spheres, 1 spp, 5 segments), c4 (10 M triangles, 4K,
@@ -22,6 +26,7 @@ Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -52,10 +57,22 @@ def algorithmic_bytes(stats, n_instances):
             + (80 * n_instances + 56) * stats["rays"] + 32 * stats["paths"])
 
 
-def build_scene(name, leaf_max, threads, grid):
+def canvas_for(name, world, scaling):
+    """Canvas of the job: the config's own, or (weak scaling of a tile-partitioned config) one of
+    `world` times the area at the same aspect ratio, sides rounded to multiples of 8."""
+    w, h, _, _, partition = CONFIGS[name]
+    if world > 1 and scaling == "weak" and partition == "tile":
+        s = math.sqrt(world)
+        w, h = int(round(w * s / 8.0)) * 8, int(round(h * s / 8.0)) * 8
+    return w, h
+
+
+def build_scene(name, leaf_max, threads, grid, canvas=None):
     from ray_tracing_amd import sphere_field_scene, terrain_scene
 
     w, h, frames, depth, _ = CONFIGS[name]
+    if canvas:
+        w, h = canvas
     if name == "c2":
         scene, cam = sphere_field_scene(w, h, n_spheres=10000, seed=1, subdivisions=2, depth=depth, threads=threads,
                                         leaf_max=leaf_max)
@@ -110,6 +127,8 @@ def main():
     ap.add_argument("--leaf-max", type=int, default=4,
                     help="largest leaf the BVH builder leaves unsplit (the reference's builder: 16, bvh.rs:75)")
     ap.add_argument("--pipeline", type=int, default=1, help="kernel: 0 plain nested loops, 1 persistent state machine")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="N > 1, tile-partitioned configs: weak = canvas area x N (default), strong = fixed canvas")
     ap.add_argument("--present", type=int, default=1, help="0: skip the gamma-corrected present image (accumulator only)")
     args = ap.parse_args()
 
@@ -132,9 +151,11 @@ def main():
     from ray_tracing_amd import _lib as L
     from ray_tracing_amd.distributed import reduce_samples, sample_split
 
-    width, height, frames_per_step, depth, partition = CONFIGS[args.config]
+    _, _, frames_per_step, depth, partition = CONFIGS[args.config]
+    width, height = canvas_for(args.config, world, args.scaling)
+    scaling = "weak" if (world > 1 and args.scaling == "weak" and partition == "tile") else "strong"
     threads = max(1, min(os.cpu_count() or 1, 16) // max(1, world))
-    scene, cam0, workload = build_scene(args.config, args.leaf_max, threads, args.grid)
+    scene, cam0, workload = build_scene(args.config, args.leaf_max, threads, args.grid, (width, height))
     n_inst = int(scene.info.num_instances)
 
     stream = torch.cuda.current_stream().cuda_stream
@@ -233,7 +254,7 @@ def main():
             "metric": "Mrays/s (primary+secondary)", "value": total_rays / elapsed / 1e6, "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "ms_per_frame": ms_per_step / frames_per_step,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": workload, "name": args.config, "partition": how,
                        "rays_per_step": total_rays / args.steps},
