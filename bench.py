@@ -153,7 +153,7 @@ def main():
 
     _, _, frames_per_step, depth, partition = CONFIGS[args.config]
     width, height = canvas_for(args.config, world, args.scaling)
-    scaling = "weak" if (world > 1 and args.scaling == "weak" and partition == "tile") else "strong"
+    scaling = "weak" if (args.scaling == "weak" and partition == "tile") else "strong"
     threads = max(1, min(os.cpu_count() or 1, 16) // max(1, world))
     scene, cam0, workload = build_scene(args.config, args.leaf_max, threads, args.grid, (width, height))
     n_inst = int(scene.info.num_instances)
