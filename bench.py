@@ -3,8 +3,8 @@
 
     python bench.py --gpus N --steps K --warmup W [--config c3]
 
-Default workload = BASELINE.json configs[2], the one the Mrays/s metric and its
-1/2/4/8-GPU figures are quoted on: a seeded ~1.0 M-triangle procedural scene at
+Default workload = the configuration the Mrays/s metric and its 1/2/4/8-GPU
+figures are quoted on ("c3"): a seeded ~1.0 M-triangle procedural scene at
 1920x1080, 16 accumulated one-sample frames per step, depth 10, scene resident
 in HBM before the timed region.  With N > 1 (launched by torch.distributed.run,
 one process per GPU) the canvas is dealt to the ranks in interleaved 8-row
@@ -17,7 +17,7 @@ about 10 ms of strictly serial steps), not by throughput.  A ray is one
 trace_ray invocation (shader/src/modules/trace.rs:195), primary and secondary
 alike; the count comes from the device's own counter.
 
-Other configs of BASELINE.json, for reference numbers (not the driver's bench
+The other configurations, for reference numbers (not the driver's bench
 line): c2 (10k tessellated spheres, 1 spp, 5 segments), c4 (10 M triangles, 4K,
 256 spp split by sample index over the GPUs with one RCCL all-reduce of the
 accumulator per step), c5 (closed box, diffuse, 9 segments).

@@ -42,7 +42,7 @@ def test_headers_compile_as_c_and_cpp_and_pin_the_layout():
             exe = os.path.join(d, name + ".out")
             subprocess.check_call([compiler, std, "-Wall", "-Werror", "-I", INCLUDE, src, "-o", exe])
             out = subprocess.check_output([exe]).decode().split("\n")
-            # the sizes of SURVEY's layout table: shared/src/lib.rs:66-183 on x86-64
+            # the sizes rustc gives the structs of shared/src/lib.rs:66-183 on x86-64
             assert out[0].split() == ["64", "16", "12", "32", "48", "4", "80", "24", "112", "40"]
             assert out[1].split() == ["16", "80", "100", "104", "64"]
     # and the ctypes mirrors agree
