@@ -496,7 +496,8 @@ __global__ __launch_bounds__(kBlock) void path_kernel_persistent(DevScene sc, De
                 // named flag first and the flags are then combined: the step is meant to be one
                 // straight run of instructions, not a tree of branches.
                 const bool slot0 = (cur & 1u) == 0u;
-                const bool near0 = desc ? first_is_1 : slot0;
+                const bool by_order = desc && first_is_1, by_slot = !desc && slot0;
+                const bool near0 = by_order || by_slot;
                 if (COUNT) {
                     const bool first_test = act && !sp_counted;
                     rec.internal_visits += desc ? 1u : 0u;
