@@ -142,9 +142,16 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the trace path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    # Rehearsal on a box with fewer GPUs than ranks: RT_BENCH_REHEARSE=1 puts every rank on GPU 0 and
+    # runs the two scalar reductions over gloo.  It exercises the N > 1 code path; its timings mean nothing.
+    rehearse = os.environ.get("RT_BENCH_REHEARSE") == "1"
+    device_index = 0 if rehearse else local_rank
+    torch.cuda.set_device(device_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
 
     from ray_tracing_amd import (App, RT_OPT_COUNTERS, RT_OPT_FRAME_STRIDE, RT_OPT_PIPELINE, RT_OPT_PRESENT,
                                  RT_OPT_SEED_MODE)
@@ -159,7 +166,7 @@ def main():
     n_inst = int(scene.info.num_instances)
 
     stream = torch.cuda.current_stream().cuda_stream
-    app = App.create(L.CamData.from_buffer_copy(cam0), scene, device=local_rank, stream=stream)
+    app = App.create(L.CamData.from_buffer_copy(cam0), scene, device=device_index, stream=stream)
     app.set_option(RT_OPT_PIPELINE, args.pipeline)
     app.set_option(RT_OPT_PRESENT, args.present)
     if partition == "tile":
@@ -223,8 +230,9 @@ def main():
     kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / max(1, args.steps)  # average kernel time per launch
     stats = app.stats()
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    r = torch.tensor([float(stats["rays"])], dtype=torch.float64, device="cuda")
+    red_dev = "cpu" if rehearse else "cuda"
+    t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+    r = torch.tensor([float(stats["rays"])], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(r, op=dist.ReduceOp.SUM)
