@@ -383,13 +383,15 @@ __global__ __launch_bounds__(kBlock) void path_kernel_persistent(DevScene sc, De
                 // `for i in first..=last`, hit.rs:111-121, for every lane that stands at a leaf --
                 // shared out over the whole wave.  The (lane, triangle) pairs of all those lanes
                 // ("owners") are numbered consecutively; worker lane w takes pair w: it borrows the
-                // owner's ray and clamp, fetches the triangle's DevTriTest and tests it (plane and
-                // range checks as in triangle_ray_intersect, then the three edge signs from the
-                // approximate edge functions; unclear signs -> the exact test on the full
-                // triangle).  Each owner then walks through its results in triangle order and keeps
-                // what the sequential loop would keep: a candidate survives when it is not beyond
-                // the best so far, so a later triangle at the same distance wins, as in hit.rs:115.
-                // One pass covers 64 pairs; what does not fit stays for the next LEAF step.
+                // owner's ray, fetches the triangle's DevTriTest and tests it (plane and lower range
+                // check as in triangle_ray_intersect, then the three edge signs from the approximate
+                // edge functions; unclear signs -> the exact test on the full triangle).  The upper
+                // range check, t > t_max, is the one part of the test that depends on the triangles
+                // before it, so it is left to the owner: each owner walks through its results in
+                // triangle order and keeps a candidate when it is not beyond the best so far --
+                // which lets a later triangle at the same distance win, as in hit.rs:115, and lets
+                // anything follow a NaN distance (a zero-area triangle), as the reference's
+                // comparisons do.  One pass covers 64 pairs; the rest stays for the next LEAF step.
                 const bool owner = phase == ST_LEAF;
                 const uint32_t c = owner ? tri_last - cur + 1u : 0u;
                 const uint32_t incl = wave_incl_sum(c), excl = incl - c;
@@ -420,7 +422,6 @@ __global__ __launch_bounds__(kBlock) void path_kernel_persistent(DevScene sc, De
                 const f2 wx = {__shfl(dpx.x, (int)o, 64), __shfl(dpx.y, (int)o, 64)};
                 const f2 wy = {__shfl(dpy.x, (int)o, 64), __shfl(dpy.y, (int)o, 64)};
                 const f2 wz = {__shfl(dpz.x, (int)o, 64), __shfl(dpz.y, (int)o, 64)};
-                const float w_hi = __shfl(rec.t, (int)o, 64);
                 const bool w_cull = (o_info & (1u << 16)) != 0u;
                 const V3 wpos = v3(wx.x, wy.x, wz.x), wdir = v3(wx.y, wy.y, wz.y);
                 // (n . pos, n . dir) in one go: dot's order, (x + y) + z, in both halves
@@ -428,9 +429,9 @@ __global__ __launch_bounds__(kBlock) void path_kernel_persistent(DevScene sc, De
                 const float dot_prod = np_nd.y;
                 const bool grazing = fabsf(dot_prod) < kEps, back = dot_prod > 0.0f;
                 float t = -(np_nd.x + b0.w) / dot_prod;
-                const bool before = t < kEps, beyond = t > w_hi;
+                const bool before = t < kEps;
                 const bool back_culled = w_cull && back;
-                const bool out = grazing || back_culled || before || beyond;
+                const bool out = grazing || back_culled || before;
                 const V3 g = (wpos + wdir * t) - v3(b1.x, b1.y, b1.z);
                 const f2 s01 = (b2.xy * splat(g.x) + b2.zw * splat(g.y)) + b3.xy * splat(g.z);
                 const TriSigns sg = tri_filter_signs(s01.x, s01.y, b1.w, b3.z, b3.w, g.x, g.y, g.z);
@@ -441,7 +442,7 @@ __global__ __launch_bounds__(kBlock) void path_kernel_persistent(DevScene sc, De
                 if (__ballot(unclear) != 0ull) {
                     if (unclear) {
                         const float4* fp = reinterpret_cast<const float4*>(&sc.tris[tri]);
-                        t = triangle_ray_intersect(fp[0], fp[1], fp[2], fp[3].x, wpos, wdir, kEps, w_hi, w_cull);
+                        t = triangle_ray_intersect(fp[0], fp[1], fp[2], fp[3].x, wpos, wdir, kEps, RT_INF, w_cull);
                     }
                 }
                 // every owner goes through its own results in order
