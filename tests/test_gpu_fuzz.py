@@ -28,16 +28,35 @@ def random_material(rng):
     return m
 
 
-def random_mesh(rng):
-    kind = rng.integers(0, 3)
+def random_mesh(rng, big=False):
+    kind = rng.integers(0, 4 if big else 3)
+    if kind == 3:  # axis-aligned rectangles: flat leaf boxes, rays along box faces, many exact ties
+        n = int(rng.integers(4, 120))
+        verts, idx = [], []
+        for q in range(n):
+            axis = int(rng.integers(0, 3))
+            c = np.round(rng.uniform(-2.0, 2.0, 3) * 4.0) / 4.0
+            e = np.round(rng.uniform(0.25, 1.5, 2) * 4.0) / 4.0
+            u, v = [a for a in range(3) if a != axis]
+            corners = []
+            for du, dv in ((0, 0), (1, 0), (1, 1), (0, 1)):
+                p = c.copy()
+                p[u] += du * e[0]
+                p[v] += dv * e[1]
+                corners.append(p)
+            b = 4 * q
+            verts += corners
+            idx += [(b, b + 1, b + 2), (b, b + 2, b + 3)]
+        return np.asarray(verts, F), np.asarray(idx, np.uint32)
     if kind == 0:  # soup of random triangles in a box, some of them degenerate or duplicated
-        n = int(rng.integers(1, 60))
+        n = int(rng.integers(1, 600 if big else 60))
         base = rng.uniform(-1.0, 1.0, (n, 1, 3))
         verts = (base + rng.uniform(-0.6, 0.6, (n, 3, 3))).reshape(-1, 3)
         idx = np.arange(3 * n, dtype=np.uint32).reshape(n, 3)
         if n > 4:
             idx[1] = idx[0]                 # the same triangle twice: equal distance, later one wins
-            verts[3 * 2 + 2] = verts[3 * 2]  # a zero-area triangle
+            if rng.integers(0, 2):
+                verts[3 * 2 + 2] = verts[3 * 2]  # a zero-area triangle: its distance is NaN and is recorded
         return verts.astype(F), idx
     if kind == 1:
         v, f = S.icosphere(int(rng.integers(0, 3)))
@@ -46,21 +65,24 @@ def random_mesh(rng):
     return np.asarray(v, F), np.asarray(f, np.uint32)
 
 
-def random_scene(rng, w, h):
+def random_scene(rng, w, h, big=False, unit=1.0):
+    """`unit` rescales object space (vertices by unit, instance scale by 1/unit): the same world-space
+    scene, with object-space coordinates inside or outside the ranges the kernels' shortcuts accept."""
     b = S.SceneBuilder()
-    n_meshes = int(rng.integers(1, 4))
+    n_meshes = int(rng.integers(1, 6 if big else 4))
     n_instances = 0
     for _ in range(n_meshes):
-        verts, idx = random_mesh(rng)
+        verts, idx = random_mesh(rng, big)
+        verts = (verts * F(unit)).astype(F)
         transforms = []
         for _ in range(int(rng.integers(1, 3))):
             axis, angle = "xyz"[int(rng.integers(0, 3))], float(rng.uniform(-math.pi, math.pi))
-            scale = [float(x) for x in rng.uniform(0.5, 2.5, 3)]
+            scale = [float(F(x) / F(unit)) for x in rng.uniform(0.5, 2.5, 3)]
             if rng.integers(0, 4) == 0:
                 scale[0] = -scale[0]  # a mirroring instance
             transforms.append(S.affine_from_srt(scale, S.quat_from_rotation(axis, angle),
                                                 [float(x) for x in rng.uniform(-3.0, 3.0, 3)]))
-        params = S.bvh_params(leaf_max=int(rng.integers(1, 9)), root_leaf_max=int(rng.choice([0, 5, 100])),
+        params = S.bvh_params(leaf_max=int(rng.integers(1, 70 if big else 9)), root_leaf_max=int(rng.choice([0, 5, 100])),
                               max_depth=int(rng.choice([3, 32])), threads=1)
         b.add_mesh(verts, idx, transforms, params)
         n_instances += len(transforms)
@@ -68,15 +90,11 @@ def random_scene(rng, w, h):
     eye = rng.uniform(-1.0, 1.0, 3)
     eye = eye / np.linalg.norm(eye) * rng.uniform(4.0, 9.0)
     cam = S.make_cam(w, h, S.look_at(tuple(eye), tuple(rng.uniform(-1.0, 1.0, 3))), fov=float(rng.uniform(40.0, 110.0)),
-                     depth=int(rng.integers(1, 7)), frame=int(rng.integers(0, 1000)))
+                     depth=int(rng.integers(1, 11 if big else 7)), frame=int(rng.integers(0, 1000)))
     return scene, cam, [random_material(rng) for _ in range(n_instances)]
 
 
-@pytest.mark.parametrize("seed", range(16))
-def test_random_scene_matches_the_oracle(seed):
-    rng = np.random.default_rng(1000 + seed)
-    w, h = int(rng.integers(5, 70)), int(rng.integers(5, 50))
-    scene, cam, materials = random_scene(rng, w, h)
+def compare(scene, cam, materials):
     # one frame when a NaN can reach the accumulator (its payload would seed the next frame)
     ref1 = O.OracleRenderer(scene, cam, trig=O.TRIG_DET, materials=materials).render(1)
     has_nan = bool(np.isnan(ref1.acc).any() or np.isnan(ref1.hit_t_bits.view(F)).any())
@@ -93,3 +111,19 @@ def test_random_scene_matches_the_oracle(seed):
         assert_bits_equal(tt, ref.triangle_tests, "triangle_tests")
         assert_bits_equal(g["acc"], ref.acc, "accumulator", nan_equal=True)
         assert g["stats"] == ref.stats_dict()
+
+
+@pytest.mark.parametrize("seed", range(64))
+def test_random_scene_matches_the_oracle(seed):
+    rng = np.random.default_rng(1000 + seed)
+    w, h = int(rng.integers(5, 70)), int(rng.integers(5, 50))
+    compare(*random_scene(rng, w, h))
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_larger_random_scene_matches_the_oracle(seed):
+    """More triangles, leaves of up to 69 triangles, axis-aligned geometry (flat boxes, exact
+    ties), depth up to 10, and object spaces rescaled by 2^-30 .. 2^30."""
+    rng = np.random.default_rng(5000 + seed)
+    unit = float(F(2.0) ** int(rng.choice([0, 0, 0, -30, -12, 12, 26, 30])))
+    compare(*random_scene(rng, int(rng.integers(40, 130)), int(rng.integers(30, 90)), big=True, unit=unit))
