@@ -167,6 +167,18 @@ int rt_parse_obj(const char* text, size_t len, rt_vertex* vertices, size_t* n_ve
 int rt_create_bvh(const rt_vertex* vertices, size_t n_vertices, rt_tri* triangles, size_t n_triangles,
                   const rt_bvh_params* params, rt_bvh* nodes, size_t* n_nodes);
 
+/* A second builder with no counterpart in the reference: a linear BVH (Morton sort,
+ * Karras 2012) built on GPU `device`, for meshes where bvh.rs's O(n log^2 n) split
+ * search on the host takes too long.  Same contract as rt_create_bvh (reorders
+ * `triangles` in place, LOCAL indices, node 0 is the root, NULL `nodes` returns only
+ * the count) and the same node format, so the tree can be uploaded, rendered by the
+ * reference's shader, or checked by the oracle like any other; it is NOT the tree
+ * bvh.rs would build.  Leaves hold `leaf_max` consecutive triangles of the sorted
+ * order (the last one possibly fewer).  A tree deeper than rt_upload_scene accepts
+ * is only found out there. */
+int rt_create_bvh_device(int device, const rt_vertex* vertices, size_t n_vertices, rt_tri* triangles,
+                         size_t n_triangles, uint32_t leaf_max, rt_bvh* nodes, size_t* n_nodes);
+
 /* SceneBuilder (mod.rs:38-134) */
 rt_scene_builder* rt_scene_builder_new(void);
 void rt_scene_builder_free(rt_scene_builder* b);

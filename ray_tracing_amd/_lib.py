@@ -122,6 +122,7 @@ SIGNATURES = {
     "rt_bvh_params_default": (None, [_P(BvhParams)]),
     "rt_parse_obj": (_i32, [C.c_char_p, _sz, _vp, _P(_sz), _vp, _P(_sz)]),
     "rt_create_bvh": (_i32, [_vp, _sz, _vp, _sz, _P(BvhParams), _vp, _P(_sz)]),
+    "rt_create_bvh_device": (_i32, [_i32, _vp, _sz, _vp, _sz, C.c_uint32, _vp, _P(_sz)]),
     "rt_scene_builder_new": (_vp, []),
     "rt_scene_builder_free": (None, [_vp]),
     "rt_scene_builder_add_obj": (_i32, [_vp, C.c_char_p, _sz, _vp, _sz, _P(BvhParams)]),

@@ -1,0 +1,270 @@
+// A BVH builder that runs on the GPU: linear BVH over Morton-sorted triangles
+// (Karras, "Maximizing Parallelism in the Construction of BVHs, Octrees, and
+// k-d Trees", 2012).  It is NOT the reference's builder (bvh.rs evaluates
+// surface-area costs at candidate splits, host_scene.cpp reproduces that): it
+// produces a different, somewhat less tight tree, two orders of magnitude
+// sooner, in the reference's own node format (shared::Bvh, 48 bytes, inclusive
+// global triangle ranges), so the result feeds rt_upload_scene -- or the
+// reference's shader -- like any other tree.
+//
+//   1. centroid of every triangle -> 63-bit Morton code inside the scene box
+//   2. radix sort of (code, triangle index) pairs            (hipCUB)
+//   3. leaves = runs of `leaf_max` consecutive sorted triangles
+//   4. one thread per internal node finds its range and split from the common
+//      prefixes of the leaves' codes (ties broken by leaf number)
+//   5. boxes bottom-up: the second child to arrive at a node merges
+#include <hip/hip_runtime.h>
+
+#include <hipcub/hipcub.hpp>
+
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "../../include/rt_hip.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+struct Box {
+    float lo[3], hi[3];
+};
+
+__device__ __forceinline__ void atomic_min_f(float* a, float v) {
+    // order-preserving for all finite floats: positives compare as ints, negatives reversed as uints
+    if (v >= 0.0f) atomicMin(reinterpret_cast<int*>(a), __float_as_int(v));
+    else atomicMax(reinterpret_cast<unsigned*>(a), __float_as_uint(v));
+}
+__device__ __forceinline__ void atomic_max_f(float* a, float v) {
+    if (v >= 0.0f) atomicMax(reinterpret_cast<int*>(a), __float_as_int(v));
+    else atomicMin(reinterpret_cast<unsigned*>(a), __float_as_uint(v));
+}
+
+__global__ void scene_bounds(const rt_vertex* v, const rt_tri* t, uint32_t n, float* bounds /* lo[3], hi[3] */) {
+    uint32_t i = blockIdx.x * kThreads + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t idx[3] = {t[i].i0, t[i].i1, t[i].i2};
+    for (int k = 0; k < 3; ++k) {
+        float c = (v[idx[0]].pos[k] + v[idx[1]].pos[k] + v[idx[2]].pos[k]) * (1.0f / 3.0f);
+        if (!(fabsf(c) < __builtin_huge_valf())) continue;  // NaN or infinite: takes no part in the scene box
+        atomic_min_f(&bounds[k], c);
+        atomic_max_f(&bounds[3 + k], c);
+    }
+}
+
+// spreads the low 21 bits of x so that two zero bits separate consecutive bits
+__device__ __forceinline__ uint64_t spread3(uint32_t x) {
+    uint64_t v = x & 0x1FFFFFu;
+    v = (v | v << 32) & 0x1F00000000FFFFull;
+    v = (v | v << 16) & 0x1F0000FF0000FFull;
+    v = (v | v << 8) & 0x100F00F00F00F00Full;
+    v = (v | v << 4) & 0x10C30C30C30C30C3ull;
+    v = (v | v << 2) & 0x1249249249249249ull;
+    return v;
+}
+
+__global__ void morton_codes(const rt_vertex* v, const rt_tri* t, uint32_t n, const float* bounds, uint64_t* keys,
+                             uint32_t* order) {
+    uint32_t i = blockIdx.x * kThreads + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t idx[3] = {t[i].i0, t[i].i1, t[i].i2};
+    uint32_t q[3];
+    for (int k = 0; k < 3; ++k) {
+        float c = (v[idx[0]].pos[k] + v[idx[1]].pos[k] + v[idx[2]].pos[k]) * (1.0f / 3.0f);
+        float ext = bounds[3 + k] - bounds[k];
+        float u = ext > 0.0f ? (c - bounds[k]) / ext : 0.0f;
+        u = u < 0.0f ? 0.0f : (u > 1.0f ? 1.0f : u);  // also maps NaN to 0
+        q[k] = (uint32_t)(u * 2097151.0f);
+    }
+    keys[i] = spread3(q[0]) << 2 | spread3(q[1]) << 1 | spread3(q[2]);
+    order[i] = i;
+}
+
+__global__ void gather_triangles(const rt_tri* in, const uint32_t* order, uint32_t n, rt_tri* out) {
+    uint32_t i = blockIdx.x * kThreads + threadIdx.x;
+    if (i < n) out[i] = in[order[i]];
+}
+
+// Length of the common prefix of the keys of leaves a and b; equal keys are told apart by
+// the leaf numbers themselves.  -1 outside the array.
+__device__ __forceinline__ int delta(const uint64_t* keys, uint32_t leaf_max, int n_leaves, int a, int b) {
+    if (b < 0 || b >= n_leaves) return -1;
+    uint64_t ka = keys[(size_t)a * leaf_max], kb = keys[(size_t)b * leaf_max];
+    if (ka == kb) return 64 + __clz((unsigned)a ^ (unsigned)b);
+    return __clzll((long long)(ka ^ kb));
+}
+
+// Internal node i (0 .. n_leaves-2).  Children are written as node numbers of the output
+// array: internal k -> k, leaf k -> n_leaves - 1 + k.
+__global__ void build_internal(const uint64_t* keys, uint32_t leaf_max, int n_leaves, uint32_t* left, uint32_t* right,
+                               uint32_t* parent) {
+    int i = blockIdx.x * kThreads + threadIdx.x;
+    if (i >= n_leaves - 1) return;
+    auto D = [&](int a, int b) { return delta(keys, leaf_max, n_leaves, a, b); };
+    const int d = D(i, i + 1) - D(i, i - 1) >= 0 ? 1 : -1;
+    const int d_min = D(i, i - d);
+    int l_max = 2;
+    while (D(i, i + l_max * d) > d_min) l_max *= 2;
+    int l = 0;
+    for (int t = l_max / 2; t >= 1; t /= 2)
+        if (D(i, i + (l + t) * d) > d_min) l += t;
+    const int j = i + l * d;
+    const int d_node = D(i, j);
+    int s = 0, t = l;
+    do {
+        t = (t + 1) / 2;
+        if (D(i, i + (s + t) * d) > d_node) s += t;
+    } while (t > 1);
+    const int gamma = i + s * d + (d < 0 ? d : 0);
+    const int lo = i < j ? i : j, hi = i < j ? j : i;
+    const uint32_t l_node = lo == gamma ? (uint32_t)(n_leaves - 1 + gamma) : (uint32_t)gamma;
+    const uint32_t r_node = hi == gamma + 1 ? (uint32_t)(n_leaves - 1 + gamma + 1) : (uint32_t)(gamma + 1);
+    left[i] = l_node;
+    right[i] = r_node;
+    parent[l_node] = (uint32_t)i;
+    parent[r_node] = (uint32_t)i;
+}
+
+__device__ __forceinline__ void store_box(rt_bvh& n, const Box& b) {
+    for (int k = 0; k < 3; ++k) {
+        n.bounding_box.min[k] = b.lo[k];
+        n.bounding_box.max[k] = b.hi[k];
+    }
+}
+
+// One thread per leaf: its box, then up the tree; the second child to reach a node merges.
+__global__ void fit_boxes(const rt_vertex* v, const rt_tri* sorted, uint32_t n_tris, uint32_t leaf_max, int n_leaves,
+                          const uint32_t* left, const uint32_t* right, const uint32_t* parent, uint32_t* arrived,
+                          rt_bvh* nodes) {
+    int leaf = blockIdx.x * kThreads + threadIdx.x;
+    if (leaf >= n_leaves) return;
+    const uint32_t first = (uint32_t)leaf * leaf_max;
+    const uint32_t last = first + leaf_max - 1u < n_tris - 1u ? first + leaf_max - 1u : n_tris - 1u;
+    Box b;
+    for (int k = 0; k < 3; ++k) {
+        b.lo[k] = __builtin_huge_valf();
+        b.hi[k] = -__builtin_huge_valf();
+    }
+    for (uint32_t t = first; t <= last; ++t) {
+        const uint32_t idx[3] = {sorted[t].i0, sorted[t].i1, sorted[t].i2};
+        for (int c = 0; c < 3; ++c)
+            for (int k = 0; k < 3; ++k) {
+                float p = v[idx[c]].pos[k];
+                b.lo[k] = p < b.lo[k] ? p : b.lo[k];
+                b.hi[k] = p > b.hi[k] ? p : b.hi[k];
+            }
+    }
+    uint32_t node = (uint32_t)(n_leaves - 1 + leaf);
+    rt_bvh out;
+    memset(&out, 0, sizeof out);
+    store_box(out, b);
+    out.child_1_or_first_tri = first;
+    out.child_2_or_last_tri = last;
+    out.mode = RT_MODE_TRIANGLES;
+    nodes[node] = out;
+    while (node != 0u) {
+        const uint32_t p = parent[node];
+        __threadfence();  // the box written above must be visible to whoever arrives second
+        if (atomicAdd(&arrived[p], 1u) == 0u) return;
+        const rt_bvh a = nodes[left[p]], c = nodes[right[p]];
+        for (int k = 0; k < 3; ++k) {
+            b.lo[k] = a.bounding_box.min[k] < c.bounding_box.min[k] ? a.bounding_box.min[k] : c.bounding_box.min[k];
+            b.hi[k] = a.bounding_box.max[k] > c.bounding_box.max[k] ? a.bounding_box.max[k] : c.bounding_box.max[k];
+        }
+        memset(&out, 0, sizeof out);
+        store_box(out, b);
+        out.child_1_or_first_tri = left[p];
+        out.child_2_or_last_tri = right[p];
+        out.mode = RT_MODE_CHILDREN;
+        nodes[p] = out;
+        node = p;
+    }
+}
+
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    hipError_t alloc(size_t n) { return hipMalloc(&p, (n ? n : 1) * sizeof(T)); }
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+};
+
+#define RT_TRY(call)                        \
+    do {                                    \
+        if ((call) != hipSuccess) return RT_ERR_HIP; \
+    } while (0)
+
+}  // namespace
+
+extern "C" int rt_create_bvh_device(int device, const rt_vertex* vertices, size_t n_vertices, rt_tri* triangles,
+                                    size_t n_triangles, uint32_t leaf_max, rt_bvh* nodes, size_t* n_nodes) {
+    if (!vertices || !triangles || !n_nodes || n_triangles == 0 || leaf_max == 0) return RT_ERR_INVALID;
+    if (n_triangles >= 0x7FFFFFFFull || n_vertices > 0xFFFFFFFFull) return RT_ERR_LIMIT;
+    for (size_t i = 0; i < n_triangles; ++i)
+        if (triangles[i].i0 >= n_vertices || triangles[i].i1 >= n_vertices || triangles[i].i2 >= n_vertices)
+            return RT_ERR_INVALID;
+    const uint32_t n = (uint32_t)n_triangles;
+    const int n_leaves = (int)((n + leaf_max - 1) / leaf_max);
+    const size_t total = 2 * (size_t)n_leaves - 1;
+    if (n_leaves > (1 << 29)) return RT_ERR_LIMIT;  // the range search doubles a leaf count in an int
+    if (!nodes) {
+        *n_nodes = total;
+        return RT_OK;
+    }
+    if (*n_nodes < total) return RT_ERR_INVALID;
+
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || device < 0 || device >= n_dev) return RT_ERR_HIP;
+    RT_TRY(hipSetDevice(device));
+    DevBuf<rt_vertex> d_v;
+    DevBuf<rt_tri> d_t, d_sorted;
+    DevBuf<float> d_bounds;
+    DevBuf<uint64_t> d_keys, d_keys_out;
+    DevBuf<uint32_t> d_order, d_order_out, d_left, d_right, d_parent, d_arrived;
+    DevBuf<rt_bvh> d_nodes;
+    DevBuf<char> d_tmp;
+    RT_TRY(d_v.alloc(n_vertices));
+    RT_TRY(d_t.alloc(n));
+    RT_TRY(d_sorted.alloc(n));
+    RT_TRY(d_bounds.alloc(6));
+    RT_TRY(d_keys.alloc(n));
+    RT_TRY(d_keys_out.alloc(n));
+    RT_TRY(d_order.alloc(n));
+    RT_TRY(d_order_out.alloc(n));
+    RT_TRY(d_left.alloc(n_leaves));
+    RT_TRY(d_right.alloc(n_leaves));
+    RT_TRY(d_parent.alloc(total));
+    RT_TRY(d_arrived.alloc(n_leaves));
+    RT_TRY(d_nodes.alloc(total));
+    RT_TRY(hipMemcpy(d_v.p, vertices, n_vertices * sizeof(rt_vertex), hipMemcpyHostToDevice));
+    RT_TRY(hipMemcpy(d_t.p, triangles, n * sizeof(rt_tri), hipMemcpyHostToDevice));
+    const float inf = __builtin_huge_valf();
+    const float init[6] = {inf, inf, inf, -inf, -inf, -inf};
+    RT_TRY(hipMemcpy(d_bounds.p, init, sizeof init, hipMemcpyHostToDevice));
+    RT_TRY(hipMemset(d_arrived.p, 0, (size_t)n_leaves * sizeof(uint32_t)));
+
+    const dim3 block(kThreads), grid_t((n + kThreads - 1) / kThreads), grid_l((n_leaves + kThreads - 1) / kThreads);
+    hipLaunchKernelGGL(scene_bounds, grid_t, block, 0, 0, d_v.p, d_t.p, n, d_bounds.p);
+    hipLaunchKernelGGL(morton_codes, grid_t, block, 0, 0, d_v.p, d_t.p, n, d_bounds.p, d_keys.p, d_order.p);
+    RT_TRY(hipGetLastError());
+    size_t tmp_bytes = 0;
+    RT_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, d_keys.p, d_keys_out.p, d_order.p, d_order_out.p, (int)n, 0,
+                                              63));
+    RT_TRY(d_tmp.alloc(tmp_bytes));
+    RT_TRY(hipcub::DeviceRadixSort::SortPairs(d_tmp.p, tmp_bytes, d_keys.p, d_keys_out.p, d_order.p, d_order_out.p, (int)n, 0,
+                                              63));
+    hipLaunchKernelGGL(gather_triangles, grid_t, block, 0, 0, d_t.p, d_order_out.p, n, d_sorted.p);
+    if (n_leaves > 1)
+        hipLaunchKernelGGL(build_internal, grid_l, block, 0, 0, d_keys_out.p, leaf_max, n_leaves, d_left.p, d_right.p,
+                           d_parent.p);
+    hipLaunchKernelGGL(fit_boxes, grid_l, block, 0, 0, d_v.p, d_sorted.p, n, leaf_max, n_leaves, d_left.p, d_right.p,
+                       d_parent.p, d_arrived.p, d_nodes.p);
+    RT_TRY(hipGetLastError());
+    RT_TRY(hipDeviceSynchronize());
+    RT_TRY(hipMemcpy(nodes, d_nodes.p, total * sizeof(rt_bvh), hipMemcpyDeviceToHost));
+    RT_TRY(hipMemcpy(triangles, d_sorted.p, n * sizeof(rt_tri), hipMemcpyDeviceToHost));
+    *n_nodes = total;
+    return RT_OK;
+}

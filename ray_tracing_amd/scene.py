@@ -88,6 +88,36 @@ def look_at(eye, target, up=(0.0, 1.0, 0.0)):
                                eye.astype(np.float32))
 
 
+def create_bvh_gpu(positions, triangles, leaf_max=4, device=0):
+    """Linear BVH built on the GPU (rt_create_bvh_device): returns the triangles in the order
+    the tree wants them and the nodes in the reference's 48-byte format (node 0 is the root)."""
+    lib = L.load()
+    v = np.zeros(len(positions), VERTEX_DT)
+    v["pos"] = np.ascontiguousarray(positions, np.float32)
+    t = np.ascontiguousarray(triangles, np.uint32).copy()
+    n = C.c_size_t(0)
+    rc = lib.rt_create_bvh_device(device, _ptr(v), len(v), _ptr(t), len(t), leaf_max, None, C.byref(n))
+    if rc != L.RT_OK:
+        raise L.RtError(rc, "rt_create_bvh_device: bad mesh")
+    nodes = np.zeros(n.value, BVH_DT)
+    rc = lib.rt_create_bvh_device(device, _ptr(v), len(v), _ptr(t), len(t), leaf_max, _ptr(nodes), C.byref(n))
+    if rc != L.RT_OK:
+        raise L.RtError(rc, "rt_create_bvh_device failed (no GPU?)")
+    return t, nodes
+
+
+def single_object_scene(positions, triangles, nodes, transforms):
+    """A scene of one mesh with a ready-made BVH (root = node 0) and one instance per transform."""
+    v = np.zeros(len(positions), VERTEX_DT)
+    v["pos"] = np.ascontiguousarray(positions, np.float32)
+    inst = np.zeros(len(transforms), INSTANCE_DT)
+    for i, t in enumerate(transforms):
+        inst["transform"][i] = np.frombuffer(bytes(t), np.float32)
+    info = L.SceneInfo(len(transforms), len(nodes), len(triangles), (C.c_float * 3)(1, -1, 1))
+    return Scene(info, v, np.ascontiguousarray(triangles, np.uint32), np.zeros(1, np.uint32), inst,
+                 np.ascontiguousarray(nodes))
+
+
 class SceneBuilder:
     """program/src/modules/mod.rs:38-134, backed by the library's C++ builder."""
 

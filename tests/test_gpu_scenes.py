@@ -179,6 +179,55 @@ def test_leaves_with_more_triangles_than_a_wave_has_lanes():
         assert (ref.hit_triangle != 0xFFFFFFFF).mean() > 0.1
 
 
+def check_tree(nodes, n_triangles, leaf_max):
+    """Every triangle in exactly one leaf, every node reachable once, boxes nested."""
+    seen_tri = np.zeros(n_triangles, np.int32)
+    seen_node = np.zeros(len(nodes), np.int32)
+    stack = [(0, None)]
+    while stack:
+        i, parent_box = stack.pop()
+        seen_node[i] += 1
+        nd = nodes[i]
+        if parent_box is not None:
+            assert (nd["min"] >= parent_box[0]).all() and (nd["max"] <= parent_box[1]).all()
+        if nd["mode"] == 1:
+            assert nd["c1"] <= nd["c2"] < n_triangles and nd["c2"] - nd["c1"] < leaf_max
+            seen_tri[nd["c1"]:nd["c2"] + 1] += 1
+        else:
+            stack += [(int(nd["c1"]), (nd["min"], nd["max"])), (int(nd["c2"]), (nd["min"], nd["max"]))]
+    assert (seen_tri == 1).all() and (seen_node == 1).all()
+
+
+@pytest.mark.parametrize("leaf_max", [1, 4, 7])
+def test_gpu_built_linear_bvh_is_a_valid_tree_and_renders_like_the_oracle(leaf_max):
+    """rt_create_bvh_device: a different tree from the reference builder's, in the same format.
+    It must be a proper BVH over a permutation of the input triangles, and the kernels must
+    agree with the oracle on it as on any other tree (the oracle walks the very same nodes)."""
+    verts, faces = S.terrain(n=40)
+    faces = np.asarray(faces, np.uint32)
+    tris, nodes = S.create_bvh_gpu(verts, faces, leaf_max=leaf_max)
+    assert sorted(map(tuple, tris.tolist())) == sorted(map(tuple, faces.tolist()))
+    assert len(nodes) == 2 * ((len(faces) + leaf_max - 1) // leaf_max) - 1
+    check_tree(nodes, len(tris), leaf_max)
+    # leaf boxes hold their triangles
+    pos = np.asarray(verts, F)
+    for nd in nodes[nodes["mode"] == 1][:200]:
+        p = pos[tris[nd["c1"]:nd["c2"] + 1].ravel()]
+        assert (p.min(0) == nd["min"]).all() and (p.max(0) == nd["max"]).all()
+    ident = S.affine_from_srt((1, 1, 1), (0, 0, 0, 1), (0, 0, 0))
+    shifted = S.affine_from_srt((0.5, 0.5, 0.5), S.quat_from_rotation("y", 0.7), (10, 25, 0))
+    scene = S.single_object_scene(pos, tris, nodes, [ident, shifted])
+    cam = S.make_cam(160, 90, S.look_at((60.0, 45.0, -70.0), (0.0, 0.0, 0.0)), fov=70.0, depth=4)
+    g, ref = check_against_oracle(scene, cam, frames=2)
+    assert (ref.hit_triangle != 0xFFFFFFFF).mean() > 0.3
+    # degenerate inputs: one triangle, and many triangles with one and the same centroid
+    one_t, one_n = S.create_bvh_gpu(pos[:3], np.array([[0, 1, 2]], np.uint32), leaf_max=4)
+    assert len(one_n) == 1 and one_n[0]["mode"] == 1 and (one_n[0]["c1"], one_n[0]["c2"]) == (0, 0)
+    same = np.tile(np.array([[0, 1, 2]], np.uint32), (100, 1))
+    same_t, same_n = S.create_bvh_gpu(pos[:3], same, leaf_max=1)
+    check_tree(same_n, 100, 1)
+
+
 def parse_obj(name):
     data = S._resource(name).encode()
     lib = L.load()
