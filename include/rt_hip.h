@@ -173,9 +173,9 @@ int rt_create_bvh(const rt_vertex* vertices, size_t n_vertices, rt_tri* triangle
  * `triangles` in place, LOCAL indices, node 0 is the root, NULL `nodes` returns only
  * the count) and the same node format, so the tree can be uploaded, rendered by the
  * reference's shader, or checked by the oracle like any other; it is NOT the tree
- * bvh.rs would build.  Leaves hold `leaf_max` consecutive triangles of the sorted
- * order (the last one possibly fewer).  A tree deeper than rt_upload_scene accepts
- * is only found out there. */
+ * bvh.rs would build.  Leaves are the subtrees of at most `leaf_max` triangles; with
+ * NULL `nodes` the count returned is an upper bound (2 n - 1), the second call returns
+ * the actual one.  A tree deeper than rt_upload_scene accepts is only found out there. */
 int rt_create_bvh_device(int device, const rt_vertex* vertices, size_t n_vertices, rt_tri* triangles,
                          size_t n_triangles, uint32_t leaf_max, rt_bvh* nodes, size_t* n_nodes);
 

@@ -9,10 +9,13 @@
 //
 //   1. centroid of every triangle -> 63-bit Morton code inside the scene box
 //   2. radix sort of (code, triangle index) pairs            (hipCUB)
-//   3. leaves = runs of `leaf_max` consecutive sorted triangles
-//   4. one thread per internal node finds its range and split from the common
-//      prefixes of the leaves' codes (ties broken by leaf number)
-//   5. boxes bottom-up: the second child to arrive at a node merges
+//   3. a binary radix tree over the sorted triangles: one thread per internal
+//      node finds its range and split from the common prefixes of the codes
+//      (ties broken by position)
+//   4. boxes bottom-up: the second child to arrive at a node merges
+//   5. every subtree of at most `leaf_max` triangles whose parent holds more
+//      becomes one leaf (its triangles are consecutive in the sorted order);
+//      the surviving nodes are numbered by a prefix sum and written out
 #include <hip/hip_runtime.h>
 
 #include <hipcub/hipcub.hpp>
@@ -88,20 +91,20 @@ __global__ void gather_triangles(const rt_tri* in, const uint32_t* order, uint32
 
 // Length of the common prefix of the keys of leaves a and b; equal keys are told apart by
 // the leaf numbers themselves.  -1 outside the array.
-__device__ __forceinline__ int delta(const uint64_t* keys, uint32_t leaf_max, int n_leaves, int a, int b) {
+__device__ __forceinline__ int delta(const uint64_t* keys, int n_leaves, int a, int b) {
     if (b < 0 || b >= n_leaves) return -1;
-    uint64_t ka = keys[(size_t)a * leaf_max], kb = keys[(size_t)b * leaf_max];
+    uint64_t ka = keys[a], kb = keys[b];
     if (ka == kb) return 64 + __clz((unsigned)a ^ (unsigned)b);
     return __clzll((long long)(ka ^ kb));
 }
 
-// Internal node i (0 .. n_leaves-2).  Children are written as node numbers of the output
-// array: internal k -> k, leaf k -> n_leaves - 1 + k.
-__global__ void build_internal(const uint64_t* keys, uint32_t leaf_max, int n_leaves, uint32_t* left, uint32_t* right,
-                               uint32_t* parent) {
+// Internal node i (0 .. n_leaves-2) of the full tree, whose leaves are single triangles.
+// Node numbers of the full tree: internal k -> k, leaf k -> n_leaves - 1 + k.
+__global__ void build_internal(const uint64_t* keys, int n_leaves, uint32_t* left, uint32_t* right, uint32_t* parent,
+                               uint32_t* range_lo, uint32_t* range_hi) {
     int i = blockIdx.x * kThreads + threadIdx.x;
     if (i >= n_leaves - 1) return;
-    auto D = [&](int a, int b) { return delta(keys, leaf_max, n_leaves, a, b); };
+    auto D = [&](int a, int b) { return delta(keys, n_leaves, a, b); };
     const int d = D(i, i + 1) - D(i, i - 1) >= 0 ? 1 : -1;
     const int d_min = D(i, i - d);
     int l_max = 2;
@@ -124,6 +127,8 @@ __global__ void build_internal(const uint64_t* keys, uint32_t leaf_max, int n_le
     right[i] = r_node;
     parent[l_node] = (uint32_t)i;
     parent[r_node] = (uint32_t)i;
+    range_lo[i] = (uint32_t)lo;
+    range_hi[i] = (uint32_t)hi;
 }
 
 __device__ __forceinline__ void store_box(rt_bvh& n, const Box& b) {
@@ -134,13 +139,11 @@ __device__ __forceinline__ void store_box(rt_bvh& n, const Box& b) {
 }
 
 // One thread per leaf: its box, then up the tree; the second child to reach a node merges.
-__global__ void fit_boxes(const rt_vertex* v, const rt_tri* sorted, uint32_t n_tris, uint32_t leaf_max, int n_leaves,
-                          const uint32_t* left, const uint32_t* right, const uint32_t* parent, uint32_t* arrived,
-                          rt_bvh* nodes) {
+__global__ void fit_boxes(const rt_vertex* v, const rt_tri* sorted, int n_leaves, const uint32_t* left,
+                          const uint32_t* right, const uint32_t* parent, uint32_t* arrived, rt_bvh* nodes) {
     int leaf = blockIdx.x * kThreads + threadIdx.x;
     if (leaf >= n_leaves) return;
-    const uint32_t first = (uint32_t)leaf * leaf_max;
-    const uint32_t last = first + leaf_max - 1u < n_tris - 1u ? first + leaf_max - 1u : n_tris - 1u;
+    const uint32_t first = (uint32_t)leaf, last = first;
     Box b;
     for (int k = 0; k < 3; ++k) {
         b.lo[k] = __builtin_huge_valf();
@@ -182,6 +185,52 @@ __global__ void fit_boxes(const rt_vertex* v, const rt_tri* sorted, uint32_t n_t
     }
 }
 
+// Full-tree node -> how many triangles it holds and where they start.
+__device__ __forceinline__ void node_range(uint32_t node, int n_leaves, const uint32_t* range_lo, const uint32_t* range_hi,
+                                           uint32_t& lo, uint32_t& hi) {
+    if (node >= (uint32_t)(n_leaves - 1)) {
+        lo = hi = node - (uint32_t)(n_leaves - 1);
+    } else {
+        lo = range_lo[node];
+        hi = range_hi[node];
+    }
+}
+
+// keep[node] = 1 when the node survives the collapse: the root, and every node whose parent
+// holds more than leaf_max triangles.
+__global__ void mark_kept(int n_leaves, uint32_t leaf_max, const uint32_t* parent, const uint32_t* range_lo,
+                          const uint32_t* range_hi, uint32_t* keep) {
+    uint32_t node = blockIdx.x * kThreads + threadIdx.x;
+    if (node >= (uint32_t)(2 * n_leaves - 1)) return;
+    uint32_t k = 1;
+    if (node != 0u) {
+        uint32_t lo, hi;
+        node_range(parent[node], n_leaves, range_lo, range_hi, lo, hi);
+        k = hi - lo + 1u > leaf_max ? 1u : 0u;
+    }
+    keep[node] = k;
+}
+
+__global__ void emit_nodes(int n_leaves, uint32_t leaf_max, const uint32_t* left, const uint32_t* right,
+                           const uint32_t* range_lo, const uint32_t* range_hi, const uint32_t* keep,
+                           const uint32_t* slot, const rt_bvh* full, rt_bvh* out) {
+    uint32_t node = blockIdx.x * kThreads + threadIdx.x;
+    if (node >= (uint32_t)(2 * n_leaves - 1) || !keep[node]) return;
+    uint32_t lo, hi;
+    node_range(node, n_leaves, range_lo, range_hi, lo, hi);
+    rt_bvh o = full[node];  // the box
+    if (hi - lo + 1u <= leaf_max) {
+        o.child_1_or_first_tri = lo;
+        o.child_2_or_last_tri = hi;
+        o.mode = RT_MODE_TRIANGLES;
+    } else {
+        o.child_1_or_first_tri = slot[left[node]];
+        o.child_2_or_last_tri = slot[right[node]];
+        o.mode = RT_MODE_CHILDREN;
+    }
+    out[slot[node]] = o;
+}
+
 template <typename T>
 struct DevBuf {
     T* p = nullptr;
@@ -206,14 +255,13 @@ extern "C" int rt_create_bvh_device(int device, const rt_vertex* vertices, size_
         if (triangles[i].i0 >= n_vertices || triangles[i].i1 >= n_vertices || triangles[i].i2 >= n_vertices)
             return RT_ERR_INVALID;
     const uint32_t n = (uint32_t)n_triangles;
-    const int n_leaves = (int)((n + leaf_max - 1) / leaf_max);
-    const size_t total = 2 * (size_t)n_leaves - 1;
+    const int n_leaves = (int)n;  // the full tree has one triangle per leaf
+    const size_t total = 2 * (size_t)n_leaves - 1;  // upper bound on what survives the collapse
     if (n_leaves > (1 << 29)) return RT_ERR_LIMIT;  // the range search doubles a leaf count in an int
     if (!nodes) {
         *n_nodes = total;
         return RT_OK;
     }
-    if (*n_nodes < total) return RT_ERR_INVALID;
 
     int n_dev = 0;
     if (hipGetDeviceCount(&n_dev) != hipSuccess || device < 0 || device >= n_dev) return RT_ERR_HIP;
@@ -222,9 +270,9 @@ extern "C" int rt_create_bvh_device(int device, const rt_vertex* vertices, size_
     DevBuf<rt_tri> d_t, d_sorted;
     DevBuf<float> d_bounds;
     DevBuf<uint64_t> d_keys, d_keys_out;
-    DevBuf<uint32_t> d_order, d_order_out, d_left, d_right, d_parent, d_arrived;
-    DevBuf<rt_bvh> d_nodes;
-    DevBuf<char> d_tmp;
+    DevBuf<uint32_t> d_order, d_order_out, d_left, d_right, d_parent, d_arrived, d_lo, d_hi, d_keep, d_slot;
+    DevBuf<rt_bvh> d_full, d_out;
+    DevBuf<char> d_tmp, d_tmp2;
     RT_TRY(d_v.alloc(n_vertices));
     RT_TRY(d_t.alloc(n));
     RT_TRY(d_sorted.alloc(n));
@@ -235,9 +283,13 @@ extern "C" int rt_create_bvh_device(int device, const rt_vertex* vertices, size_
     RT_TRY(d_order_out.alloc(n));
     RT_TRY(d_left.alloc(n_leaves));
     RT_TRY(d_right.alloc(n_leaves));
+    RT_TRY(d_lo.alloc(n_leaves));
+    RT_TRY(d_hi.alloc(n_leaves));
     RT_TRY(d_parent.alloc(total));
     RT_TRY(d_arrived.alloc(n_leaves));
-    RT_TRY(d_nodes.alloc(total));
+    RT_TRY(d_keep.alloc(total));
+    RT_TRY(d_slot.alloc(total));
+    RT_TRY(d_full.alloc(total));
     RT_TRY(hipMemcpy(d_v.p, vertices, n_vertices * sizeof(rt_vertex), hipMemcpyHostToDevice));
     RT_TRY(hipMemcpy(d_t.p, triangles, n * sizeof(rt_tri), hipMemcpyHostToDevice));
     const float inf = __builtin_huge_valf();
@@ -245,7 +297,8 @@ extern "C" int rt_create_bvh_device(int device, const rt_vertex* vertices, size_
     RT_TRY(hipMemcpy(d_bounds.p, init, sizeof init, hipMemcpyHostToDevice));
     RT_TRY(hipMemset(d_arrived.p, 0, (size_t)n_leaves * sizeof(uint32_t)));
 
-    const dim3 block(kThreads), grid_t((n + kThreads - 1) / kThreads), grid_l((n_leaves + kThreads - 1) / kThreads);
+    const dim3 block(kThreads), grid_t((n + kThreads - 1) / kThreads),
+        grid_n((unsigned)((total + kThreads - 1) / kThreads));
     hipLaunchKernelGGL(scene_bounds, grid_t, block, 0, 0, d_v.p, d_t.p, n, d_bounds.p);
     hipLaunchKernelGGL(morton_codes, grid_t, block, 0, 0, d_v.p, d_t.p, n, d_bounds.p, d_keys.p, d_order.p);
     RT_TRY(hipGetLastError());
@@ -257,14 +310,28 @@ extern "C" int rt_create_bvh_device(int device, const rt_vertex* vertices, size_
                                               63));
     hipLaunchKernelGGL(gather_triangles, grid_t, block, 0, 0, d_t.p, d_order_out.p, n, d_sorted.p);
     if (n_leaves > 1)
-        hipLaunchKernelGGL(build_internal, grid_l, block, 0, 0, d_keys_out.p, leaf_max, n_leaves, d_left.p, d_right.p,
-                           d_parent.p);
-    hipLaunchKernelGGL(fit_boxes, grid_l, block, 0, 0, d_v.p, d_sorted.p, n, leaf_max, n_leaves, d_left.p, d_right.p,
-                       d_parent.p, d_arrived.p, d_nodes.p);
+        hipLaunchKernelGGL(build_internal, grid_t, block, 0, 0, d_keys_out.p, n_leaves, d_left.p, d_right.p, d_parent.p,
+                           d_lo.p, d_hi.p);
+    hipLaunchKernelGGL(fit_boxes, grid_t, block, 0, 0, d_v.p, d_sorted.p, n_leaves, d_left.p, d_right.p, d_parent.p,
+                       d_arrived.p, d_full.p);
+    hipLaunchKernelGGL(mark_kept, grid_n, block, 0, 0, n_leaves, leaf_max, d_parent.p, d_lo.p, d_hi.p, d_keep.p);
+    RT_TRY(hipGetLastError());
+    size_t tmp2_bytes = 0;
+    RT_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp2_bytes, d_keep.p, d_slot.p, (int)total));
+    RT_TRY(d_tmp2.alloc(tmp2_bytes));
+    RT_TRY(hipcub::DeviceScan::ExclusiveSum(d_tmp2.p, tmp2_bytes, d_keep.p, d_slot.p, (int)total));
+    uint32_t last_keep = 0, last_slot = 0;
+    RT_TRY(hipMemcpy(&last_keep, d_keep.p + (total - 1), 4, hipMemcpyDeviceToHost));
+    RT_TRY(hipMemcpy(&last_slot, d_slot.p + (total - 1), 4, hipMemcpyDeviceToHost));
+    const size_t kept = (size_t)last_slot + last_keep;
+    if (*n_nodes < kept) return RT_ERR_INVALID;
+    RT_TRY(d_out.alloc(kept));
+    hipLaunchKernelGGL(emit_nodes, grid_n, block, 0, 0, n_leaves, leaf_max, d_left.p, d_right.p, d_lo.p, d_hi.p, d_keep.p,
+                       d_slot.p, d_full.p, d_out.p);
     RT_TRY(hipGetLastError());
     RT_TRY(hipDeviceSynchronize());
-    RT_TRY(hipMemcpy(nodes, d_nodes.p, total * sizeof(rt_bvh), hipMemcpyDeviceToHost));
+    RT_TRY(hipMemcpy(nodes, d_out.p, kept * sizeof(rt_bvh), hipMemcpyDeviceToHost));
     RT_TRY(hipMemcpy(triangles, d_sorted.p, n * sizeof(rt_tri), hipMemcpyDeviceToHost));
-    *n_nodes = total;
+    *n_nodes = kept;
     return RT_OK;
 }

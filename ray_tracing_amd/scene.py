@@ -103,7 +103,7 @@ def create_bvh_gpu(positions, triangles, leaf_max=4, device=0):
     rc = lib.rt_create_bvh_device(device, _ptr(v), len(v), _ptr(t), len(t), leaf_max, _ptr(nodes), C.byref(n))
     if rc != L.RT_OK:
         raise L.RtError(rc, "rt_create_bvh_device failed (no GPU?)")
-    return t, nodes
+    return t, nodes[:n.value].copy()
 
 
 def single_object_scene(positions, triangles, nodes, transforms):

@@ -207,7 +207,7 @@ def test_gpu_built_linear_bvh_is_a_valid_tree_and_renders_like_the_oracle(leaf_m
     faces = np.asarray(faces, np.uint32)
     tris, nodes = S.create_bvh_gpu(verts, faces, leaf_max=leaf_max)
     assert sorted(map(tuple, tris.tolist())) == sorted(map(tuple, faces.tolist()))
-    assert len(nodes) == 2 * ((len(faces) + leaf_max - 1) // leaf_max) - 1
+    assert 2 * ((len(faces) + leaf_max - 1) // leaf_max) - 1 <= len(nodes) <= 2 * len(faces) - 1
     check_tree(nodes, len(tris), leaf_max)
     # leaf boxes hold their triangles
     pos = np.asarray(verts, F)
