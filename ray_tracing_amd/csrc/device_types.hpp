@@ -138,6 +138,13 @@ struct DevQueue {
     uint32_t first_item[9];  // queue i covers items [first_item[i], first_item[i + 1])
     uint32_t tiles_x;        // 8x8 tiles per row of tiles
     int w_ctl, w_box, w_leaf, w_setup;  // vote weights of the four kinds of step
+    // Cost-aware order (both optional).  `order` permutes the tiles inside each queue's range:
+    // position p of the queue stands for tile order[p].  `cost` receives, per tile, the path
+    // lengths of this launch; order_tiles_kernel turns them into the next launch's order, dearest
+    // tiles first, so that the longest chains of dependent steps start early and the launch does
+    // not end on a few lanes finishing them alone.
+    const uint32_t* order;
+    uint32_t* cost;
 };
 
 struct DevFrame {

@@ -190,8 +190,10 @@ __device__ __forceinline__ f2 splat(float v) { return f2{v, v}; }
 __device__ __forceinline__ f2 vmin(f2 a, f2 b) { return __builtin_elementwise_min(a, b); }
 __device__ __forceinline__ f2 vmax(f2 a, f2 b) { return __builtin_elementwise_max(a, b); }
 
+// The fast variant is held to 128 registers (4 waves per SIMD); the counting variant, which
+// carries the counters and the scheduling profile as well, is left alone.
 template <int STACK_N, bool COUNT>
-__global__ __launch_bounds__(kBlock) void path_kernel_persistent(DevScene sc, DevCam cam, DevRows rows, DevFrame fr,
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((COUNT || STACK_N > 32) ? 1 : 4))) void path_kernel_persistent(DevScene sc, DevCam cam, DevRows rows, DevFrame fr,
                                                                  DevQueue q, uint32_t n_frames) {
     __shared__ uint32_t s_stack[STACK_N * kBlock];
     __shared__ uint32_t s_tmp[kBlock];  // 64 words per wave: who works for whom in a LEAF step
@@ -208,7 +210,7 @@ __global__ __launch_bounds__(kBlock) void path_kernel_persistent(DevScene sc, De
     uint32_t ctl = CT_NEW_PIXEL;
     uint32_t queues_tried = 0;  // wave-uniform: how many queues this wave has found empty
     // pixel state
-    uint32_t x = 0, y = 0, idx = 0;
+    uint32_t x = 0, y = 0, tile = 0;
     float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     uint32_t frame = cam.frame;
     float fwm = cam.frames_without_move;
@@ -273,14 +275,14 @@ __global__ __launch_bounds__(kBlock) void path_kernel_persistent(DevScene sc, De
                     const uint32_t k = base + (uint32_t)__popcll(wm & lanes_below);
                     if (k < q_size) {
                         const uint32_t item = q_first + k;
-                        const uint32_t tile = item >> 6, l = item & 63u;
+                        const uint32_t l = item & 63u;
+                        tile = q.order ? q.order[item >> 6] : item >> 6;
                         const uint32_t tile_y = tile / q.tiles_x, tile_x = tile - tile_y * q.tiles_x;
                         x = tile_x * 8u + (l & 7u);
                         const uint32_t ly = tile_y * 8u + (l >> 3);
                         y = global_row(rows, ly);
                         if (x < cam.W && ly < rows.local_rows && y < cam.H) {
-                            idx = x + y * cam.W;
-                            acc = reinterpret_cast<const float4*>(fr.acc)[idx];
+                            acc = reinterpret_cast<const float4*>(fr.acc)[x + y * cam.W];
                             frame = cam.frame;
                             fwm = cam.frames_without_move;
                             frames_left = n_frames;
@@ -319,6 +321,7 @@ __global__ __launch_bounds__(kBlock) void path_kernel_persistent(DevScene sc, De
                         break;
                     }
                     // every instance has been visited: the rest of trace_ray, trace.rs:97-172
+                    const uint32_t idx = x + y * cam.W;
                     if (seg == 0 && fr.hit_triangle) {
                         fr.hit_triangle[idx] = rec.triangle_id;
                         fr.hit_instance[idx] = rec.instance_id;
@@ -349,6 +352,7 @@ __global__ __launch_bounds__(kBlock) void path_kernel_persistent(DevScene sc, De
                     frames_left -= 1u;
                     if (frames_left == 0u) {
                         reinterpret_cast<float4*>(fr.acc)[idx] = acc;
+                        if (q.cost) atomicAdd(&q.cost[tile], seg);  // length of the pixel's last path
                         ctl = CT_NEW_PIXEL;
                         break;
                     }
@@ -614,6 +618,29 @@ __global__ __launch_bounds__(kBlock) void present_kernel(DevCam cam, DevRows row
     reinterpret_cast<float4*>(fr.present)[idx] = gamma_correct(present_from_acc(fwm_last, acc));
 }
 
+// Next launch's tile order from this launch's costs: one workgroup per queue range, a counting
+// sort into 32 cost classes, dearest class first.  Within a class the order is whatever the
+// atomics make it: the order of pixels changes no pixel's value.
+__global__ __launch_bounds__(kBlock) void order_tiles_kernel(DevQueue q, uint32_t* order_out) {
+    __shared__ uint32_t s_count[32], s_start[32];
+    const uint32_t t0 = q.first_item[blockIdx.x] >> 6, t1 = q.first_item[blockIdx.x + 1] >> 6;
+    if (threadIdx.x < 32) s_count[threadIdx.x] = 0;
+    __syncthreads();
+    // a full tile's cost is 64 pixels x 1..10+ segments; 24 per class keeps the classes fine enough
+    auto cls = [](uint32_t c) { return c / 24u < 31u ? c / 24u : 31u; };
+    for (uint32_t t = t0 + threadIdx.x; t < t1; t += kBlock) atomicAdd(&s_count[cls(q.cost[t])], 1u);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t at = 0;
+        for (int c = 31; c >= 0; --c) {
+            s_start[c] = at;
+            at += s_count[c];
+        }
+    }
+    __syncthreads();
+    for (uint32_t t = t0 + threadIdx.x; t < t1; t += kBlock) order_out[t0 + atomicAdd(&s_start[cls(q.cost[t])], 1u)] = t;
+}
+
 hipError_t launch_path_kernel(const DevScene& sc, const DevCam& cam, const DevRows& rows, const DevFrame& fr,
                               uint32_t n_frames, uint32_t stack_needed, bool count, hipStream_t stream) {
     const uint32_t tiles_x = (cam.W + kTileW - 1) / kTileW;
@@ -635,8 +662,8 @@ hipError_t launch_path_kernel(const DevScene& sc, const DevCam& cam, const DevRo
 }
 
 hipError_t launch_persistent_kernel(const DevScene& sc, const DevCam& cam, const DevRows& rows, const DevFrame& fr,
-                                    DevQueue q, uint32_t n_frames, uint32_t stack_needed, bool count,
-                                    uint32_t n_blocks, hipStream_t stream) {
+                                    DevQueue q, uint32_t* order_out, uint32_t n_frames, uint32_t stack_needed,
+                                    bool count, uint32_t n_blocks, hipStream_t stream) {
     // 8x8-pixel tiles of this context's rows, split into 8 contiguous ranges
     q.tiles_x = (cam.W + 7u) / 8u;
     const uint32_t tiles_y = (rows.local_rows + 7u) / 8u;
@@ -645,6 +672,7 @@ hipError_t launch_persistent_kernel(const DevScene& sc, const DevCam& cam, const
     for (uint32_t i = 0; i <= 8; ++i) q.first_item[i] = (uint32_t)(((uint64_t)n_tiles * i) / 8u) * 64u;
     hipError_t e = hipMemsetAsync(q.head, 0, 8 * 32 * sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
+    if (q.cost && (e = hipMemsetAsync(q.cost, 0, (size_t)n_tiles * sizeof(uint32_t), stream)) != hipSuccess) return e;
     dim3 grid(n_blocks), block(kBlock);
 #define RT_LAUNCH(N, C) \
     hipLaunchKernelGGL((path_kernel_persistent<N, C>), grid, block, 0, stream, sc, cam, rows, fr, q, n_frames)
@@ -657,7 +685,12 @@ hipError_t launch_persistent_kernel(const DevScene& sc, const DevCam& cam, const
     }
 #undef RT_LAUNCH
     hipError_t e2 = hipGetLastError();
-    if (e2 != hipSuccess || !fr.present) return e2;
+    if (e2 != hipSuccess) return e2;
+    if (q.cost && order_out) {
+        hipLaunchKernelGGL(order_tiles_kernel, dim3(8), block, 0, stream, q, order_out);
+        if ((e2 = hipGetLastError()) != hipSuccess) return e2;
+    }
+    if (!fr.present) return hipSuccess;
     const uint32_t n_pixels = cam.W * rows.local_rows;
     // frames_without_move of the last frame, advanced the way the kernel advances it
     float fwm_last = cam.frames_without_move;
@@ -668,6 +701,10 @@ hipError_t launch_persistent_kernel(const DevScene& sc, const DevCam& cam, const
     }
     hipLaunchKernelGGL(present_kernel, dim3((n_pixels + kBlock - 1) / kBlock), block, 0, stream, cam, rows, fr, fwm_last);
     return hipGetLastError();
+}
+
+uint32_t persistent_tile_count(const DevCam& cam, const DevRows& rows) {
+    return ((cam.W + 7u) / 8u) * ((rows.local_rows + 7u) / 8u);
 }
 
 int persistent_blocks_per_cu(uint32_t stack_needed, bool count) {

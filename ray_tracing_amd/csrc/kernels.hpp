@@ -15,10 +15,14 @@ hipError_t launch_path_kernel(const DevScene& sc, const DevCam& cam, const DevRo
 
 // Persistent whole-path kernel (per-lane state machine, vote-scheduled, work
 // queues).  `q.head` must point at 8 * 32 words of device memory; `n_blocks`
-// is the number of resident workgroups to launch.
+// is the number of resident workgroups to launch.  With `q.cost` and `order_out`
+// (one word per 8x8 tile each) the launch also leaves the tile order for the
+// next launch of the same canvas in `order_out`; `q.order`, when set, is such an
+// order from an earlier launch.
 hipError_t launch_persistent_kernel(const DevScene& sc, const DevCam& cam, const DevRows& rows, const DevFrame& fr,
-                                    DevQueue q, uint32_t n_frames, uint32_t stack_needed, bool count,
-                                    uint32_t n_blocks, hipStream_t stream);
+                                    DevQueue q, uint32_t* order_out, uint32_t n_frames, uint32_t stack_needed,
+                                    bool count, uint32_t n_blocks, hipStream_t stream);
+uint32_t persistent_tile_count(const DevCam& cam, const DevRows& rows);
 
 // Workgroups of the persistent kernel one CU can hold (occupancy query).
 int persistent_blocks_per_cu(uint32_t stack_needed, bool count);

@@ -43,6 +43,14 @@ struct rt_ctx {
     uint32_t* d_tritests = nullptr;
     DevStats* d_stats = nullptr;
     uint32_t* d_queue = nullptr;  // work-queue heads of the persistent kernel
+    // cost-aware tile order: costs of the last launch, the order derived from them (two buffers:
+    // one read by a launch, the other written after it), and the canvas partition they belong to
+    uint32_t* d_tile_cost = nullptr;
+    uint32_t* d_tile_order[2] = {nullptr, nullptr};
+    uint32_t tile_capacity = 0;
+    int order_current = -1;  // which of d_tile_order holds a usable order; -1: none
+    uint32_t order_sig[5] = {0, 0, 0, 0, 0};
+    bool tile_order_enabled = true;
     int n_cus = 0;
     int vote_w[4] = {2, 1, 3, 2};  // vote weights: control, box, triangle, instance set-up steps
 
@@ -219,13 +227,39 @@ int render(rt_ctx* c, const rt_cam_data& cam, uint32_t n_frames) {
         q.w_box = c->vote_w[1];
         q.w_leaf = c->vote_w[2];
         q.w_setup = c->vote_w[3];
+        uint32_t* order_out = nullptr;
+        if (c->tile_order_enabled) {
+            const uint32_t n_tiles = persistent_tile_count(dc, rows);
+            const uint32_t sig[5] = {dc.W, dc.H, rows.strip_h, rows.rank, rows.world};
+            if (n_tiles > c->tile_capacity) {
+                free_dev(c->d_tile_cost);
+                free_dev(c->d_tile_order[0]);
+                free_dev(c->d_tile_order[1]);
+                c->tile_capacity = 0;
+                RT_HIP(c, hipMalloc(&c->d_tile_cost, (size_t)n_tiles * 4));
+                RT_HIP(c, hipMalloc(&c->d_tile_order[0], (size_t)n_tiles * 4));
+                RT_HIP(c, hipMalloc(&c->d_tile_order[1], (size_t)n_tiles * 4));
+                c->tile_capacity = n_tiles;
+                c->order_current = -1;
+            }
+            if (std::memcmp(sig, c->order_sig, sizeof sig) != 0) {
+                c->order_current = -1;  // another canvas or another share of it: start from the plain order
+                std::memcpy(c->order_sig, sig, sizeof sig);
+            }
+            q.cost = c->d_tile_cost;
+            q.order = c->order_current >= 0 ? c->d_tile_order[c->order_current] : nullptr;
+            const int next = c->order_current == 0 ? 1 : 0;
+            order_out = c->d_tile_order[next];
+            c->order_current = next;
+        }
         int per_cu = persistent_blocks_per_cu(stack_needed, count);
         if (const char* e = std::getenv("RT_BLOCKS_PER_CU")) {  // tuning knob: fewer resident workgroups
             int v = std::atoi(e);
             if (v >= 1 && v < per_cu) per_cu = v;
         }
         const uint32_t n_blocks = (uint32_t)(c->n_cus * per_cu);
-        RT_HIP(c, launch_persistent_kernel(sc, dc, rows, fr, q, n_frames, stack_needed, count, n_blocks, c->stream));
+        RT_HIP(c, launch_persistent_kernel(sc, dc, rows, fr, q, order_out, n_frames, stack_needed, count, n_blocks,
+                                           c->stream));
     }
     RT_HIP(c, hipEventRecord(c->ev1, c->stream));
     c->timed = true;
@@ -262,6 +296,7 @@ int rt_create(int device, rt_ctx** out) {
     hipDeviceProp_t prop;
     if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return bail("hipGetDeviceProperties", e);
     c->n_cus = prop.multiProcessorCount;
+    if (std::getenv("RT_NO_TILE_ORDER")) c->tile_order_enabled = false;  // tuning knob
     if (const char* w = std::getenv("RT_VOTE_WEIGHTS")) {
         int a = 1, b = 1, d = 1, s = 1;
         if (std::sscanf(w, "%d,%d,%d,%d", &a, &b, &d, &s) == 4 && a > 0 && b > 0 && d > 0 && s > 0) {
@@ -283,6 +318,9 @@ void rt_destroy(rt_ctx* c) {
     free_frame(c);
     free_dev(c->d_stats);
     free_dev(c->d_queue);
+    free_dev(c->d_tile_cost);
+    free_dev(c->d_tile_order[0]);
+    free_dev(c->d_tile_order[1]);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     delete c;
