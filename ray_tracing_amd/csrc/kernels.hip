@@ -13,6 +13,8 @@ using namespace dev;
 namespace {
 
 constexpr int kBlock = 256;  // 4 waves
+constexpr uint32_t kPT = 8;         // side of the persistent kernel's pixel tiles
+constexpr uint32_t kPTShift = 6;   // log2(kPT * kPT)
 constexpr int kTileW = 32;   // plain kernel: block tile 32 x 8 pixels, one 8x8 tile per wave
 constexpr int kTileH = 8;
 
@@ -275,11 +277,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((COUNT |
                     const uint32_t k = base + (uint32_t)__popcll(wm & lanes_below);
                     if (k < q_size) {
                         const uint32_t item = q_first + k;
-                        const uint32_t l = item & 63u;
-                        tile = q.order ? q.order[item >> 6] : item >> 6;
+                        const uint32_t l = item & (kPT * kPT - 1u);
+                        tile = q.order ? q.order[item >> kPTShift] : item >> kPTShift;
                         const uint32_t tile_y = tile / q.tiles_x, tile_x = tile - tile_y * q.tiles_x;
-                        x = tile_x * 8u + (l & 7u);
-                        const uint32_t ly = tile_y * 8u + (l >> 3);
+                        x = tile_x * kPT + (l & (kPT - 1u));
+                        const uint32_t ly = tile_y * kPT + l / kPT;
                         y = global_row(rows, ly);
                         if (x < cam.W && ly < rows.local_rows && y < cam.H) {
                             acc = reinterpret_cast<const float4*>(fr.acc)[x + y * cam.W];
@@ -623,11 +625,11 @@ __global__ __launch_bounds__(kBlock) void present_kernel(DevCam cam, DevRows row
 // atomics make it: the order of pixels changes no pixel's value.
 __global__ __launch_bounds__(kBlock) void order_tiles_kernel(DevQueue q, uint32_t* order_out) {
     __shared__ uint32_t s_count[32], s_start[32];
-    const uint32_t t0 = q.first_item[blockIdx.x] >> 6, t1 = q.first_item[blockIdx.x + 1] >> 6;
+    const uint32_t t0 = q.first_item[blockIdx.x] >> kPTShift, t1 = q.first_item[blockIdx.x + 1] >> kPTShift;
     if (threadIdx.x < 32) s_count[threadIdx.x] = 0;
     __syncthreads();
     // a full tile's cost is 64 pixels x 1..10+ segments; 24 per class keeps the classes fine enough
-    auto cls = [](uint32_t c) { return c / 24u < 31u ? c / 24u : 31u; };
+    auto cls = [](uint32_t c) { return c * 64u / (kPT * kPT * 24u) < 31u ? c * 64u / (kPT * kPT * 24u) : 31u; };
     for (uint32_t t = t0 + threadIdx.x; t < t1; t += kBlock) atomicAdd(&s_count[cls(q.cost[t])], 1u);
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -665,11 +667,11 @@ hipError_t launch_persistent_kernel(const DevScene& sc, const DevCam& cam, const
                                     DevQueue q, uint32_t* order_out, uint32_t n_frames, uint32_t stack_needed,
                                     bool count, uint32_t n_blocks, hipStream_t stream) {
     // 8x8-pixel tiles of this context's rows, split into 8 contiguous ranges
-    q.tiles_x = (cam.W + 7u) / 8u;
-    const uint32_t tiles_y = (rows.local_rows + 7u) / 8u;
+    q.tiles_x = (cam.W + kPT - 1u) / kPT;
+    const uint32_t tiles_y = (rows.local_rows + kPT - 1u) / kPT;
     const uint32_t n_tiles = q.tiles_x * tiles_y;
     if (n_tiles == 0 || n_blocks == 0) return hipSuccess;
-    for (uint32_t i = 0; i <= 8; ++i) q.first_item[i] = (uint32_t)(((uint64_t)n_tiles * i) / 8u) * 64u;
+    for (uint32_t i = 0; i <= 8; ++i) q.first_item[i] = (uint32_t)(((uint64_t)n_tiles * i) / 8u) * (kPT * kPT);
     hipError_t e = hipMemsetAsync(q.head, 0, 8 * 32 * sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
     if (q.cost && (e = hipMemsetAsync(q.cost, 0, (size_t)n_tiles * sizeof(uint32_t), stream)) != hipSuccess) return e;
@@ -704,7 +706,7 @@ hipError_t launch_persistent_kernel(const DevScene& sc, const DevCam& cam, const
 }
 
 uint32_t persistent_tile_count(const DevCam& cam, const DevRows& rows) {
-    return ((cam.W + 7u) / 8u) * ((rows.local_rows + 7u) / 8u);
+    return ((cam.W + kPT - 1u) / kPT) * ((rows.local_rows + kPT - 1u) / kPT);
 }
 
 int persistent_blocks_per_cu(uint32_t stack_needed, bool count) {
