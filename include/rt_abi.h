@@ -133,13 +133,24 @@ typedef struct __attribute__((aligned(16))) rt_cam_data {
 enum {
     RT_MAT_GENERIC  = 0, /* GenericMaterial   material.rs:71-194  */
     RT_MAT_NORMAL   = 1, /* NormalMaterial    material.rs:262-320 */
-    RT_MAT_EMISSIVE = 2  /* EmmissiveMaterial material.rs:340-387 */
+    RT_MAT_EMISSIVE = 2, /* EmmissiveMaterial material.rs:340-387 */
+    /* The reference implements these but never selects them (trace.rs:161-167). */
+    RT_MAT_REFRACTIVE = 3, /* RefractiveMaterial material.rs:389-487: uses ior            */
+    RT_MAT_UV         = 4, /* UVMaterial         material.rs:489-530: uv is always (0,0),  */
+                           /* trace.rs:159, so the path stops with colour * 0              */
+    /* These two have get_color / get_next_ray_dir but no `impl Material` in the reference
+     * (material.rs:196-260); their bxdf is assembled the way NormalMaterial::bxdf
+     * (material.rs:299-319) assembles its own: next ray from get_next_ray_dir at the hit
+     * point, colour from get_color. */
+    RT_MAT_DIFFUSE    = 5, /* DiffuseMaterial    material.rs:196-225: uses color           */
+    RT_MAT_METAL      = 6, /* MetalMaterial      material.rs:227-260: uses color, roughness */
+    RT_MAT_KIND_COUNT = 7
 };
 
 typedef struct rt_material {
     uint32_t kind;             /* RT_MAT_*                                  */
     uint32_t backface_culling; /* 0/1, Material::backface_culling            */
-    float color[3];            /* Generic: albedo; Emissive: light colour    */
+    float color[3];            /* Generic/Diffuse/Metal: albedo; Emissive: light */
     float specular;
     float specular_roughness;
     float roughness;

@@ -521,6 +521,68 @@ static int emissive_bxdf(const rt_material* m, v3* color, ray_t* ray, v3 normal,
     return STATE_STOP;
 }
 
+/* RefractiveMaterial::bxdf, material.rs:389-487 */
+static int refractive_bxdf(const rt_material* m, ray_t* ray, v3 normal, float t, uint32_t* seed) {
+    ray_t in_ray = *ray;
+    /* get_next_ray_dir, material.rs:444-462 */
+    int front_face = v3_dot(in_ray.dir, normal) < 0.0f;
+    float refraction_ratio = front_face ? 1.0f / m->ior : m->ior;
+    float cos_theta = v3_dot(normal, v3_neg(in_ray.dir));
+    float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+    /* reflectance, material.rs:399-405 */
+    float r0 = (1.0f - m->ior) / (1.0f + m->ior);
+    r0 *= r0;
+    float reflectance = r0 + (1.0f - r0) * powi5(1.0f - cos_theta);
+    v3 direction;
+    /* `||` short-circuits: no random draw under total internal reflection */
+    if (refraction_ratio * sin_theta > 1.0f || reflectance > orc_rand_float(seed, 0.0f, 1.0f)) {
+        /* reflect, material.rs:407-410; glam Vec3::reflect = self - 2 * self.dot(n) * n */
+        direction = v3_normalize(v3_sub(in_ray.dir, v3_scale(normal, 2.0f * v3_dot(in_ray.dir, normal))));
+    } else {
+        /* refract, material.rs:412-432 */
+        v3 unit_in = v3_normalize(in_ray.dir);
+        float c = fminf(v3_dot(v3_neg(unit_in), normal), 1.0f);
+        v3 r_out_perp = v3_scale(v3_add(unit_in, v3_scale(normal, c)), refraction_ratio);
+        v3 r_out_parallel = v3_scale(v3_neg(normal), sqrtf(fabsf(1.0f - v3_dot(r_out_perp, r_out_perp))));
+        direction = v3_add(r_out_perp, r_out_parallel);
+    }
+    ray->pos = v3_add(in_ray.pos, v3_scale(in_ray.dir, t));
+    ray->dir = direction;
+    return STATE_RAY; /* get_color returns the colour unchanged, material.rs:434-442 */
+}
+
+/* UVMaterial::bxdf, material.rs:489-530, with uv = (0, 0) (trace.rs:159) */
+static int uv_bxdf(v3* color, ray_t* ray, float t) {
+    ray_t in_ray = *ray;
+    ray->pos = v3_add(in_ray.pos, v3_scale(in_ray.dir, t));
+    ray->dir = v3_new(0.0f, 0.0f, 0.0f);
+    *color = v3_mul(*color, v3_new(0.0f, 0.0f, 0.0f));
+    return STATE_STOP;
+}
+
+/* DiffuseMaterial, material.rs:196-225 */
+static int diffuse_bxdf(const rt_material* m, v3* color, ray_t* ray, v3 normal, float t, uint32_t* seed,
+                        int trig_mode) {
+    ray_t in_ray = *ray;
+    v3 direction = diffuse_ray_direction(seed, normal, trig_mode);
+    ray->pos = v3_add(in_ray.pos, v3_scale(in_ray.dir, t));
+    ray->dir = direction;
+    *color = v3_mul(*color, v3_ld(m->color));
+    return STATE_RAY;
+}
+
+/* MetalMaterial, material.rs:227-260 */
+static int metal_bxdf(const rt_material* m, v3* color, ray_t* ray, v3 normal, float t, uint32_t* seed,
+                      int trig_mode) {
+    ray_t in_ray = *ray;
+    v3 new_ray = v3_normalize(v3_sub(in_ray.dir, v3_scale(normal, 2.0f * v3_dot(in_ray.dir, normal))));
+    v3 rand_vec = v3_normalize(diffuse_ray_direction(seed, normal, trig_mode));
+    ray->pos = v3_add(in_ray.pos, v3_scale(in_ray.dir, t));
+    ray->dir = v3_lerp(new_ray, rand_vec, m->roughness);
+    *color = v3_mul(*color, v3_ld(m->color));
+    return STATE_RAY;
+}
+
 /* BackgroundMaterial::get_stop_color, material.rs:332-337 */
 static inline v3 sky_color(v3 ray_dir) {
     v3 temp = v3_normalize(ray_dir);
@@ -528,6 +590,34 @@ static inline v3 sky_color(v3 ray_dir) {
     return v3_add(v3_scale(v3_new(1.0f, 1.0f, 1.0f), 1.0f - factor), v3_scale(v3_new(0.5f, 0.7f, 1.0f), factor));
 }
 void orc_sky(const float dir[3], float out[3]) { v3_st(out, sky_color(v3_ld(dir))); }
+
+/* One material response on its own, for known-answer tests: colour, ray and seed are updated in
+ * place exactly as trace_ray's dispatch (trace.rs:161-172) would; returns the RayReturnState. */
+static int dispatch_bxdf(const rt_material* m, v3* color, ray_t* ray, v3 normal, float t, uint32_t* seed,
+                         int trig_mode) {
+    switch (m->kind) {
+        case RT_MAT_GENERIC: return generic_bxdf(m, color, ray, normal, t, seed, trig_mode);
+        case RT_MAT_NORMAL: return normal_bxdf(color, ray, normal, t, seed, trig_mode);
+        case RT_MAT_REFRACTIVE: return refractive_bxdf(m, ray, normal, t, seed);
+        case RT_MAT_UV: return uv_bxdf(color, ray, t);
+        case RT_MAT_DIFFUSE: return diffuse_bxdf(m, color, ray, normal, t, seed, trig_mode);
+        case RT_MAT_METAL: return metal_bxdf(m, color, ray, normal, t, seed, trig_mode);
+        default: return emissive_bxdf(m, color, ray, normal, t);
+    }
+}
+
+int orc_bxdf(const rt_material* m, float color[3], float pos[3], float dir[3], const float normal[3], float t,
+             uint32_t* seed, int trig_mode) {
+    v3 c = v3_ld(color);
+    ray_t r;
+    r.pos = v3_ld(pos);
+    r.dir = v3_ld(dir);
+    int state = dispatch_bxdf(m, &c, &r, v3_ld(normal), t, seed, trig_mode);
+    v3_st(color, c);
+    v3_st(pos, r.pos);
+    v3_st(dir, r.dir);
+    return state;
+}
 
 static inline void material_for(const orc_scene* s, uint32_t instance_id, rt_material* m) {
     if (s->materials && instance_id < s->n_materials) *m = s->materials[instance_id];
@@ -587,11 +677,7 @@ static int trace_ray(const orc_scene* s, const rt_cam_data* cam, ray_t* self, ui
 
     rt_material m;
     material_for(s, record.instance_id, &m);
-    switch (m.kind) {
-        case RT_MAT_GENERIC: return generic_bxdf(&m, color, self, normal, record.t, seed, trig_mode);
-        case RT_MAT_NORMAL: return normal_bxdf(color, self, normal, record.t, seed, trig_mode);
-        default: return emissive_bxdf(&m, color, self, normal, record.t);
-    }
+    return dispatch_bxdf(&m, color, self, normal, record.t, seed, trig_mode);
 }
 
 typedef struct {

@@ -84,6 +84,11 @@ void orc_transform_vector3(const rt_affine3a* m, const float v[3], float out[3])
 void orc_camera_ray(const rt_cam_data* cam, float px, float py, float pos[3], float dir[3]);
 void orc_sky(const float dir[3], float out[3]);
 void orc_default_material(uint32_t instance_id, rt_material* out);
+/* One Material::bxdf call (material.rs) for a world-space ray that hit at distance t on a
+ * surface with the given unit normal; colour, ray and seed are updated in place.  Returns the
+ * RayReturnState: 0 Absorb, 1 Stop, 2 Ray. */
+int orc_bxdf(const rt_material* m, float color[3], float pos[3], float dir[3], const float normal[3], float t,
+             uint32_t* seed, int trig_mode);
 /* Mesh::hit for one object-space ray; updates the record in place (hit.rs:65-134).
  * rec = {triangle_id, t_bits, instance_id, triangle_tests, box_tests}. */
 void orc_mesh_hit(const orc_scene* s, uint32_t bvh_root, const float pos[3], const float dir[3],

@@ -88,6 +88,7 @@ RT_ERR_INVALID, RT_ERR_HIP, RT_ERR_NO_SCENE, RT_ERR_LIMIT = -1, -2, -3, -4
 RT_OPT_PIPELINE, RT_OPT_PROBE_HITS, RT_OPT_COUNTERS, RT_OPT_PRESENT = 1, 2, 3, 4
 RT_OPT_FRAME_STRIDE, RT_OPT_SEED_MODE = 5, 6
 RT_MAT_GENERIC, RT_MAT_NORMAL, RT_MAT_EMISSIVE = 0, 1, 2
+RT_MAT_REFRACTIVE, RT_MAT_UV, RT_MAT_DIFFUSE, RT_MAT_METAL = 3, 4, 5, 6
 RT_DEBUG_NONE, RT_DEBUG_TRIANGLE_INTERSECTION, RT_DEBUG_BVH_INTERSECTION = 0, 1, 2
 
 _vp, _sz, _u32, _i32, _f = C.c_void_p, C.c_size_t, C.c_uint32, C.c_int, C.c_float

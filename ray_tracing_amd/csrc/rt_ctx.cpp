@@ -410,7 +410,7 @@ int rt_set_materials(rt_ctx* c, const rt_material* materials, size_t n) {
         rt_material m;
         if (materials) m = materials[i];
         else default_material(i, m);
-        if (m.kind > RT_MAT_EMISSIVE) return fail(c, RT_ERR_INVALID, "unknown material kind");
+        if (m.kind >= RT_MAT_KIND_COUNT) return fail(c, RT_ERR_INVALID, "unknown material kind");
         apply_material(c->h_instances[i], m);
     }
     RT_HIP(c, hipSetDevice(c->device));

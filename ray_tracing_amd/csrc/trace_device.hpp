@@ -433,6 +433,60 @@ RT_DEV int emissive_bxdf(const DevInstance& m, V3& color, Ray& ray, V3 normal, f
     return STATE_STOP;
 }
 
+// RefractiveMaterial::bxdf, material.rs:389-487
+RT_DEV int refractive_bxdf(const DevInstance& m, Ray& ray, V3 normal, float t, uint32_t& seed) {
+    Ray in_ray = ray;
+    bool front_face = dot(in_ray.dir, normal) < 0.0f;
+    float refraction_ratio = front_face ? 1.0f / m.ior : m.ior;
+    float cos_theta = dot(normal, -in_ray.dir);
+    float sin_theta = __builtin_sqrtf(1.0f - cos_theta * cos_theta);
+    float r0 = (1.0f - m.ior) / (1.0f + m.ior);
+    r0 *= r0;
+    float reflectance = r0 + (1.0f - r0) * powi5(1.0f - cos_theta);
+    V3 direction;
+    // the random number is drawn only when the first test fails (material.rs:451)
+    if (refraction_ratio * sin_theta > 1.0f || reflectance > rand_float(seed, 0.0f, 1.0f)) {
+        direction = normalize(in_ray.dir - normal * (2.0f * dot(in_ray.dir, normal)));
+    } else {
+        V3 unit_in = normalize(in_ray.dir);
+        float c = fminf(dot(-unit_in, normal), 1.0f);
+        V3 r_out_perp = (unit_in + normal * c) * refraction_ratio;
+        V3 r_out_parallel = -normal * __builtin_sqrtf(fabsf(1.0f - dot(r_out_perp, r_out_perp)));
+        direction = r_out_perp + r_out_parallel;
+    }
+    ray.pos = in_ray.pos + in_ray.dir * t;
+    ray.dir = direction;
+    return STATE_RAY;
+}
+
+// UVMaterial::bxdf, material.rs:489-530; uv is (0, 0) at the only call site (trace.rs:159)
+RT_DEV int uv_bxdf(V3& color, Ray& ray, float t) {
+    Ray in_ray = ray;
+    ray.pos = in_ray.pos + in_ray.dir * t;
+    ray.dir = v3(0.0f, 0.0f, 0.0f);
+    color = color * v3(0.0f, 0.0f, 0.0f);
+    return STATE_STOP;
+}
+
+// DiffuseMaterial, material.rs:196-225, assembled the way NormalMaterial::bxdf is
+RT_DEV int diffuse_bxdf(const DevInstance& m, V3& color, Ray& ray, V3 normal, float t, uint32_t& seed) {
+    Ray in_ray = ray;
+    V3 direction = diffuse_ray_direction(seed, normal);
+    ray.pos = in_ray.pos + in_ray.dir * t;
+    ray.dir = direction;
+    color = color * ld3(m.color);
+    return STATE_RAY;
+}
+
+// MetalMaterial, material.rs:227-260: the same arithmetic as GenericMaterial::reflect
+RT_DEV int metal_bxdf(const DevInstance& m, V3& color, Ray& ray, V3 normal, float t, uint32_t& seed) {
+    Ray in_ray = ray;
+    ray.dir = generic_reflect(in_ray.dir, normal, m.roughness, seed);
+    ray.pos = in_ray.pos + in_ray.dir * t;
+    color = color * ld3(m.color);
+    return STATE_RAY;
+}
+
 // BackgroundMaterial::get_stop_color, material.rs:332-337
 RT_DEV V3 sky_color(V3 ray_dir) {
     V3 temp = normalize(ray_dir);
@@ -476,6 +530,10 @@ RT_DEV int shade(const DevScene& sc, const DevCam& cam, const HitRecord& record,
     V3 normal = normalize(cross(w0 - w1, w0 - w2));
     if (inst.mat_kind == 0u) return generic_bxdf(inst, color, self, normal, record.t, seed);
     if (inst.mat_kind == 1u) return normal_bxdf(color, self, normal, record.t, seed);
+    if (inst.mat_kind == 3u) return refractive_bxdf(inst, self, normal, record.t, seed);
+    if (inst.mat_kind == 4u) return uv_bxdf(color, self, record.t);
+    if (inst.mat_kind == 5u) return diffuse_bxdf(inst, color, self, normal, record.t, seed);
+    if (inst.mat_kind == 6u) return metal_bxdf(inst, color, self, normal, record.t, seed);
     return emissive_bxdf(inst, color, self, normal, record.t);
 }
 

@@ -138,3 +138,68 @@ def triangle_ray_intersect(p0, p1, p2, pos, direction, t_lo, t_hi, backface_cull
 
 def is_inf(t):
     return bits(t) in (0x7F800000, 0xFF800000)
+
+
+# ---- the materials the reference implements but never selects (material.rs:196-260, 389-530) ----
+def det_sphere(lib, seed):
+    """rand_vec_in_unit_sphere (material.rs:25-35) with the oracle's deterministic sin/cos"""
+    seed, phi = rand_float(seed, 0.0, F(2.0) * PI)
+    seed, costheta = rand_float(seed, -1.0, 1.0)
+    theta = acos_approx(costheta)
+    st = F(lib.orc_det_sin(theta))
+    return seed, np.array([st * F(lib.orc_det_cos(phi)), st * F(lib.orc_det_sin(phi)), costheta], F)
+
+
+def diffuse_ray_direction(lib, seed, normal):
+    seed, v = det_sphere(lib, seed)
+    res = v + normal
+    if dot(res, res) < F(np.finfo(F).eps):
+        return seed, normal
+    return seed, normalize(res)
+
+
+def reflect(d, n):
+    return d - n * (F(2.0) * dot(d, n))
+
+
+def lerp(a, b, s):
+    """glam >= 0.25 Vec3::lerp"""
+    return a * (F(1.0) - F(s)) + b * F(s)
+
+
+def powi5(x):
+    a = x * x
+    a = a * a
+    return x * a
+
+
+def refractive_bxdf(ior, pos, d, n, t, seed):
+    """RefractiveMaterial::bxdf, material.rs:444-486; returns (seed, new_pos, new_dir)"""
+    ior = F(ior)
+    with np.errstate(all="ignore"):
+        front = dot(d, n) < 0
+        ratio = F(1.0) / ior if front else ior
+        cos_theta = dot(n, -d)
+        sin_theta = np.sqrt(F(1.0) - cos_theta * cos_theta)
+        r0 = (F(1.0) - ior) / (F(1.0) + ior)
+        r0 = r0 * r0
+        reflectance = r0 + (F(1.0) - r0) * powi5(F(1.0) - cos_theta)
+        total = ratio * sin_theta > 1
+        if not total:
+            seed, u = rand_float(seed, 0.0, 1.0)
+        if total or reflectance > u:
+            nd = normalize(reflect(d, n))
+        else:
+            unit_in = normalize(d)
+            c = _fmin(dot(-unit_in, n), F(1.0))
+            perp = (unit_in + n * c) * ratio
+            par = -n * np.sqrt(np.abs(F(1.0) - dot(perp, perp)))
+            nd = perp + par
+        return seed, pos + d * F(t), nd
+
+
+def metal_bxdf(lib, color, roughness, pos, d, n, t, seed):
+    """MetalMaterial, material.rs:239-259; returns (seed, new_pos, new_dir)"""
+    new_ray = normalize(reflect(d, n))
+    seed, rv = diffuse_ray_direction(lib, seed, n)
+    return seed, pos + d * F(t), lerp(new_ray, normalize(rv), roughness)

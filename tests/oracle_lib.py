@@ -74,6 +74,8 @@ def load():
     lib.orc_sky.argtypes = [F3, F3]
     lib.orc_default_material.restype = None
     lib.orc_default_material.argtypes = [u32, C.POINTER(L.Material)]
+    lib.orc_bxdf.restype = C.c_int
+    lib.orc_bxdf.argtypes = [C.POINTER(L.Material), F3, F3, F3, F3, f, C.POINTER(u32), C.c_int]
     lib.orc_mesh_hit.restype = None
     lib.orc_mesh_hit.argtypes = [C.POINTER(OrcScene), u32, F3, F3, f, f, u32, C.c_int, C.POINTER(u32)]
     lib.orc_get_color.restype = None

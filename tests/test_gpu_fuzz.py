@@ -8,7 +8,8 @@ import numpy as np
 import pytest
 
 import oracle_lib as O
-from ray_tracing_amd import (Material, RT_MAT_EMISSIVE, RT_MAT_GENERIC, RT_MAT_NORMAL)
+from ray_tracing_amd import (Material, RT_MAT_DIFFUSE, RT_MAT_EMISSIVE, RT_MAT_GENERIC, RT_MAT_METAL, RT_MAT_NORMAL,
+                             RT_MAT_REFRACTIVE, RT_MAT_UV)
 from ray_tracing_amd import scene as S
 from helpers import assert_bits_equal, gpu_render
 
@@ -16,9 +17,13 @@ pytestmark = pytest.mark.gpu
 F = np.float32
 
 
-def random_material(rng):
+REFERENCE_KINDS = [RT_MAT_GENERIC, RT_MAT_NORMAL, RT_MAT_EMISSIVE]  # the three the reference selects
+ALL_KINDS = REFERENCE_KINDS + [RT_MAT_REFRACTIVE, RT_MAT_REFRACTIVE, RT_MAT_UV, RT_MAT_DIFFUSE, RT_MAT_METAL]
+
+
+def random_material(rng, kinds=REFERENCE_KINDS):
     m = Material()
-    m.kind = int(rng.choice([RT_MAT_GENERIC, RT_MAT_NORMAL, RT_MAT_EMISSIVE]))
+    m.kind = int(rng.choice(kinds))
     m.backface_culling = int(rng.integers(0, 2))
     m.color[:] = [float(x) for x in rng.uniform(0.1, 3.0, 3)]
     m.specular = float(rng.choice([0.0, 0.0, rng.uniform(0.0, 1.0)]))
@@ -65,7 +70,7 @@ def random_mesh(rng, big=False):
     return np.asarray(v, F), np.asarray(f, np.uint32)
 
 
-def random_scene(rng, w, h, big=False, unit=1.0):
+def random_scene(rng, w, h, big=False, unit=1.0, kinds=REFERENCE_KINDS):
     """`unit` rescales object space (vertices by unit, instance scale by 1/unit): the same world-space
     scene, with object-space coordinates inside or outside the ranges the kernels' shortcuts accept."""
     b = S.SceneBuilder()
@@ -91,7 +96,7 @@ def random_scene(rng, w, h, big=False, unit=1.0):
     eye = eye / np.linalg.norm(eye) * rng.uniform(4.0, 9.0)
     cam = S.make_cam(w, h, S.look_at(tuple(eye), tuple(rng.uniform(-1.0, 1.0, 3))), fov=float(rng.uniform(40.0, 110.0)),
                      depth=int(rng.integers(1, 11 if big else 7)), frame=int(rng.integers(0, 1000)))
-    return scene, cam, [random_material(rng) for _ in range(n_instances)]
+    return scene, cam, [random_material(rng, kinds) for _ in range(n_instances)]
 
 
 def compare(scene, cam, materials):
@@ -127,3 +132,12 @@ def test_larger_random_scene_matches_the_oracle(seed):
     rng = np.random.default_rng(5000 + seed)
     unit = float(F(2.0) ** int(rng.choice([0, 0, 0, -30, -12, 12, 26, 30])))
     compare(*random_scene(rng, int(rng.integers(40, 130)), int(rng.integers(30, 90)), big=True, unit=unit))
+
+
+@pytest.mark.parametrize("seed", range(32))
+def test_random_scene_with_every_material_kind_matches_the_oracle(seed):
+    """As above, with the materials the reference implements but never selects in the draw."""
+    rng = np.random.default_rng(9000 + seed)
+    big = seed % 4 == 3
+    w, h = (int(rng.integers(40, 100)), int(rng.integers(30, 70))) if big else (int(rng.integers(5, 70)), int(rng.integers(5, 50)))
+    compare(*random_scene(rng, w, h, big=big, kinds=ALL_KINDS))

@@ -295,6 +295,83 @@ def test_sky_closed_form():
     assert [fb(v) for v in out] == [fb(w) for w in want]
 
 
+def vb(x):
+    return np.asarray(x, dtype=F).view(np.uint32).tolist()
+
+
+def _bxdf(kind, color, pos, d, n, t, seed, mcolor=(1, 1, 1), roughness=0.0, ior=0.0):
+    m = L.Material()
+    m.kind, m.backface_culling = kind, 1
+    m.color[:] = [float(x) for x in mcolor]
+    m.roughness, m.ior = float(roughness), float(ior)
+    c, p, dd = O.f3(*color), O.f3(*pos), O.f3(*d)
+    s = C.c_uint32(seed)
+    state = lib.orc_bxdf(C.byref(m), c, p, dd, O.f3(*n), F(t), C.byref(s), O.TRIG_DET)
+    return state, np.array(c[:], F), np.array(p[:], F), np.array(dd[:], F), s.value
+
+
+def test_refractive_material_hand_cases():
+    # straight down onto glass of ior 1.5 from outside: cos = 1, reflectance = r0 = 0.04, a draw
+    # above that refracts; the refracted ray keeps going straight down
+    seed = 12345
+    _, u = R.rand_float(seed, 0.0, 1.0)
+    assert u > 0.04
+    state, c, p, d, s = _bxdf(L.RT_MAT_REFRACTIVE, (0.5, 0.25, 1), (0, 2, 0), (0, -1, 0), (0, 1, 0), 2.0, seed, ior=1.5)
+    assert state == 2 and list(c) == [0.5, 0.25, 1.0] and list(p) == [0, 0, 0]
+    assert list(d) == [0, -1, 0] and s == R.xor_shift(seed)
+    # from inside at 60 degrees: ior * sin = 1.299 > 1, total internal reflection, no draw
+    d_in = np.array([math.sin(math.radians(60)), math.cos(math.radians(60)), 0], F)
+    state, c, p, d, s = _bxdf(L.RT_MAT_REFRACTIVE, (1, 1, 1), (0, 0, 0), d_in, (0, 1, 0), 1.0, seed, ior=1.5)
+    assert state == 2 and s == seed
+    assert np.allclose(d, [d_in[0], -d_in[1], 0], atol=1e-6)
+
+
+def test_unselected_materials_match_numpy_restatement_on_random_inputs():
+    rng = np.random.default_rng(77)
+    for i in range(400):
+        d = R.normalize(rng.normal(size=3).astype(F))
+        n = R.normalize(rng.normal(size=3).astype(F))
+        pos = rng.uniform(-5, 5, 3).astype(F)
+        t = F(rng.uniform(0.01, 20.0))
+        seed = int(rng.integers(1, 2**32))
+        ior = F(rng.choice([1.0, 1.33, 1.5, 2.4]))
+        mcolor = rng.uniform(0.1, 2.0, 3).astype(F)
+        color = rng.uniform(0.0, 1.0, 3).astype(F)
+        rough = F(rng.uniform(0.0, 1.0))
+
+        state, c, p, nd, s = _bxdf(L.RT_MAT_REFRACTIVE, color, pos, d, n, t, seed, ior=ior)
+        rs, rp, rd = R.refractive_bxdf(ior, pos, d, n, t, seed)
+        assert state == 2 and s == rs and vb(c) == vb(color)
+        assert vb(p) == vb(rp) and vb(nd) == vb(rd), i
+
+        state, c, p, nd, s = _bxdf(L.RT_MAT_METAL, color, pos, d, n, t, seed, mcolor=mcolor, roughness=rough)
+        rs, rp, rd = R.metal_bxdf(lib, mcolor, rough, pos, d, n, t, seed)
+        assert state == 2 and s == rs and vb(c) == vb(color * mcolor)
+        assert vb(p) == vb(rp) and vb(nd) == vb(rd), i
+
+        state, c, p, nd, s = _bxdf(L.RT_MAT_DIFFUSE, color, pos, d, n, t, seed, mcolor=mcolor)
+        rs, rd = R.diffuse_ray_direction(lib, seed, n)
+        assert state == 2 and s == rs and vb(c) == vb(color * mcolor)
+        assert vb(p) == vb(pos + d * t) and vb(nd) == vb(rd), i
+
+        state, c, p, nd, s = _bxdf(L.RT_MAT_UV, color, pos, d, n, t, seed)
+        assert state == 1 and s == seed and list(c) == [0, 0, 0] and list(nd) == [0, 0, 0]
+        assert vb(p) == vb(pos + d * t)
+
+
+def test_metal_is_the_generic_material_without_specular_and_ior():
+    """MetalMaterial's direction (material.rs:249-259) is GenericMaterial::reflect_regular's
+    (material.rs:113-124) operation for operation."""
+    rng = np.random.default_rng(5)
+    for _ in range(50):
+        d = R.normalize(rng.normal(size=3).astype(F))
+        n = R.normalize(rng.normal(size=3).astype(F))
+        args = ((0.3, 0.6, 0.9), (1, 2, 3), d, n, 1.5, int(rng.integers(1, 2**32)))
+        a = _bxdf(L.RT_MAT_METAL, *args, mcolor=(0.5, 0.7, 0.2), roughness=0.3)
+        b = _bxdf(L.RT_MAT_GENERIC, *args, mcolor=(0.5, 0.7, 0.2), roughness=0.3)
+        assert a[0] == b[0] and a[4] == b[4] and all(vb(x) == vb(y) for x, y in zip(a[1:4], b[1:4]))
+
+
 def test_default_materials_are_the_reference_constants():
     m = L.Material()
     lib.orc_default_material(0, C.byref(m))
