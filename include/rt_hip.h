@@ -31,6 +31,7 @@ extern "C" {
 #define RT_ERR_HIP (-2)      /* a HIP runtime call failed                     */
 #define RT_ERR_NO_SCENE (-3) /* render/read before rt_upload_scene            */
 #define RT_ERR_LIMIT (-4)    /* scene exceeds a capacity of this build        */
+#define RT_ERR_IO (-5)       /* a file could not be written                   */
 
 typedef struct rt_ctx rt_ctx;
 
@@ -234,6 +235,17 @@ uint64_t rt_selftest_slab_filter(uint64_t n, uint64_t seed, uint64_t* n_clear);
  * evaluation of hit.rs:160-188.  Must return 0.  *n_clear receives the number of
  * cases that were called clear-cut. */
 uint64_t rt_selftest_tri_filter(uint64_t n, uint64_t seed, uint64_t* n_clear);
+
+/* Image files, in place of the reference's copy of binding 8 into the swapchain
+ * (vulkan.rs:1045-1101).  Both take a host buffer of width*height RGBA floats, as
+ * rt_read_present / rt_read_acc fill it, row 0 at the top.
+ * rt_save_png: 8-bit RGB of the displayed image (values clamped to [0,1], NaN -> 0),
+ *   with a gAMA chunk for the 1/2.2 exponent of shader/src/lib.rs:101-105.
+ * rt_save_exr: 32-bit float R,G,B scan lines, uncompressed; every value is multiplied
+ *   by `scale` (1 / (frames_without_move + 1) turns the accumulator into mean radiance,
+ *   shader/src/lib.rs:99-100). */
+int rt_save_png(const char* path, const float* rgba, uint32_t width, uint32_t height);
+int rt_save_exr(const char* path, const float* rgba, uint32_t width, uint32_t height, float scale);
 
 const char* rt_version(void);
 

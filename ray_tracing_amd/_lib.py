@@ -84,7 +84,7 @@ for _t, _n in _SIZES.items():
     assert C.sizeof(_t) == _n, (_t.__name__, C.sizeof(_t), _n)
 
 RT_OK = 0
-RT_ERR_INVALID, RT_ERR_HIP, RT_ERR_NO_SCENE, RT_ERR_LIMIT = -1, -2, -3, -4
+RT_ERR_INVALID, RT_ERR_HIP, RT_ERR_NO_SCENE, RT_ERR_LIMIT, RT_ERR_IO = -1, -2, -3, -4, -5
 RT_OPT_PIPELINE, RT_OPT_PROBE_HITS, RT_OPT_COUNTERS, RT_OPT_PRESENT = 1, 2, 3, 4
 RT_OPT_FRAME_STRIDE, RT_OPT_SEED_MODE = 5, 6
 RT_MAT_GENERIC, RT_MAT_NORMAL, RT_MAT_EMISSIVE = 0, 1, 2
@@ -97,6 +97,7 @@ _P = C.POINTER
 # name -> (restype, argtypes).  One entry per declaration of include/rt_hip.h.
 SIGNATURES = {
     "rt_version": (C.c_char_p, []),
+
     "rt_create": (_i32, [_i32, _P(_vp)]),
     "rt_destroy": (None, [_vp]),
     "rt_last_error": (C.c_char_p, [_vp]),
@@ -109,6 +110,8 @@ SIGNATURES = {
     "rt_render_frame": (_i32, [_vp, _P(CamData)]),
     "rt_render_frames": (_i32, [_vp, _P(CamData), _u32]),
     "rt_synchronize": (_i32, [_vp]),
+    "rt_save_png": (_i32, [C.c_char_p, _vp, C.c_uint32, C.c_uint32]),
+    "rt_save_exr": (_i32, [C.c_char_p, _vp, C.c_uint32, C.c_uint32, C.c_float]),
     "rt_read_acc": (_i32, [_vp, _vp, _sz]),
     "rt_read_present": (_i32, [_vp, _vp, _sz]),
     "rt_write_acc": (_i32, [_vp, _vp, _sz, _u32, _u32]),

@@ -120,6 +120,27 @@ class App:
         self._check(self._lib.rt_read_present(self._ctx, _ptr(out), self._n()))
         return out
 
+    # ---- image files, in place of the swapchain copy (vulkan.rs:1045-1101) ------
+    def save_png(self, path):
+        """The displayed image (binding 8) as an 8-bit PNG."""
+        img = self.read_present()
+        h, w = self._shape()
+        rc = self._lib.rt_save_png(str(path).encode(), _ptr(img), w, h)
+        if rc != 0:
+            raise L.RtError(rc, f"could not write {path}")
+
+    def save_exr(self, path, samples=None):
+        """Mean linear radiance as a float OpenEXR file: the accumulator divided by the number
+        of samples in it (default: cam_data.frames_without_move, which render() keeps equal to
+        that number, main.rs:147-148)."""
+        acc = self.read_acc()
+        if samples is None:
+            samples = max(1.0, float(self.cam_data.frames_without_move))
+        h, w = self._shape()
+        rc = self._lib.rt_save_exr(str(path).encode(), _ptr(acc), w, h, 1.0 / float(samples))
+        if rc != 0:
+            raise L.RtError(rc, f"could not write {path}")
+
     def write_acc(self, rgba):
         rgba = np.ascontiguousarray(rgba, np.float32)
         h, w = self._shape()
