@@ -404,10 +404,14 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((COUNT |
                 const uint32_t room = excl < 64u ? 64u - excl : 0u;
                 const uint32_t n_proc = c < room ? c : room;
                 // worker w -> owner: owners mark the first of their pairs, a running maximum spreads the mark
-                // (volatile: other lanes' stores must be seen, the compiler may not forward this lane's own)
-                volatile uint32_t* const tmp = &s_tmp[threadIdx.x & ~63u];
+                // (a wave's LDS operations complete in program order; the empty asm statements keep the
+                // compiler from forwarding this lane's own store to its load, which must see other
+                // lanes' stores)
+                uint32_t* const tmp = &s_tmp[threadIdx.x & ~63u];
                 tmp[lane] = 0u;
+                asm volatile("" ::: "memory");
                 if (n_proc != 0u) tmp[excl] = lane + 1u;
+                asm volatile("" ::: "memory");
                 const uint32_t own1 = wave_incl_max(tmp[lane]);
                 const uint32_t o = own1 != 0u ? own1 - 1u : lane;
                 // the owner's first pair, pair count and culling rule travel in one word
