@@ -181,8 +181,11 @@ __global__ __launch_bounds__(kBlock) void path_kernel(DevScene sc, DevCam cam, D
 //    covering a contiguous range of 8x8 pixel tiles; a wave that drains its own
 //    queue moves on to the next one.
 // ---------------------------------------------------------------------------
-enum : uint32_t { ST_CONTROL = 0, ST_DESC = 1, ST_POP = 2, ST_LEAF = 3, ST_DEAD = 4, ST_SETUP = 5 };
-enum : uint32_t { CT_NEW_PIXEL = 0, CT_NEW_PATH = 1, CT_START_SEGMENT = 2, CT_NEXT_INSTANCE = 3 };
+enum : uint32_t { ST_CONTROL = 0, ST_DESC = 1, ST_POP = 2, ST_LEAF = 3, ST_DEAD = 4 };
+enum : uint32_t { CT_NEW_PIXEL = 0, CT_NEW_PATH = 1, CT_START_SEGMENT = 2, CT_NEXT_INSTANCE = 3, CT_SHADE = 4 };
+// instance records read with a wave-uniform index: the constant address space lets them come
+// through the scalar cache into scalar registers
+typedef const __attribute__((address_space(4))) DevInstance* ConstInstance;
 constexpr uint32_t kNoItem = 0xFFFFFFFFu;
 
 typedef float f2 __attribute__((ext_vector_type(2)));
@@ -208,6 +211,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((COUNT |
     unsigned long long sched_iters[4] = {0, 0, 0, 0}, sched_lanes[4] = {0, 0, 0, 0}, sched_cycles[4] = {0, 0, 0, 0},
                        sched_wait[4] = {0, 0, 0, 0};  // wave-uniform
 
+    const ConstInstance inst_base = (ConstInstance)(uintptr_t)sc.instances;
     uint32_t phase = n_frames > 0 ? ST_CONTROL : ST_DEAD;
     uint32_t ctl = CT_NEW_PIXEL;
     uint32_t queues_tried = 0;  // wave-uniform: how many queues this wave has found empty
@@ -234,7 +238,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((COUNT |
     f4 it0 = {0.0f, 0.0f, 0.0f, 0.0f}, it1 = it0, it2 = it0, it3 = it0;  // the pending item
     uint32_t cur = 0;  // ST_DESC / ST_POP: (node index << 1) | child slot;  ST_LEAF: triangle index
     uint32_t tri_last = 0, sp = 0;
-    bool sp_counted = false;  // ST_POP: the pending child came off the stack (its test is already counted)
 
     // Wave-uniform condition: lanes that have run out of pixels stay in the loop, inert, until
     // the whole wave is done, so that the cross-lane operations of the LEAF step always see all
@@ -246,10 +249,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((COUNT |
         const int w_ctl = __popcll(__ballot(phase == ST_CONTROL)) * q.w_ctl;
         const int w_box = __popcll(__ballot(phase == ST_DESC || phase == ST_POP)) * q.w_box;
         const int w_leaf = __popcll(__ballot(phase == ST_LEAF)) * q.w_leaf;
-        const int w_setup = __popcll(__ballot(phase == ST_SETUP)) * q.w_setup;
         int pick = 1, w_best = w_box;
         if (w_leaf > w_best) pick = 2, w_best = w_leaf;
-        if (w_setup > w_best) pick = 3, w_best = w_setup;
         if (w_ctl > w_best) pick = 0;
         if (COUNT) {
             // profile only: how long the prefetched item still takes to arrive
@@ -257,8 +258,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((COUNT |
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             sched_wait[pick] += __builtin_readcyclecounter() - t0;
             sched_iters[pick] += 1;
-            sched_lanes[pick] += (unsigned)(pick == 0 ? w_ctl / q.w_ctl : pick == 1 ? w_box / q.w_box
-                                            : pick == 2 ? w_leaf / q.w_leaf : w_setup / q.w_setup);
+            sched_lanes[pick] += (unsigned)(pick == 0 ? w_ctl / q.w_ctl : pick == 1 ? w_box / q.w_box : w_leaf / q.w_leaf);
         }
 
         if (pick == 0) {
@@ -295,8 +295,101 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((COUNT |
                     }
                 }
             }
-            if (phase == ST_CONTROL && ctl != CT_NEW_PIXEL) {
-                for (;;) {
+            // Two rounds of: (1) the instance loop of trace_ray (trace.rs:76-94) for every lane that
+            // stands between two instances, (2) the rest of trace_ray and whatever follows it for
+            // the lanes whose instances are exhausted.  A lane that starts a new segment in (2)
+            // of the first round finds its first instance in (1) of the second.
+            for (int round = 0; round < 2; ++round) {
+                // (1) One pass over the instance indices, in order; index u is wave-uniform, so the
+                // instance record comes through the scalar cache.  A lane takes part at its own
+                // index: the ray moves into the instance's object space, the root box is tested
+                // against the clamp (EPS, record.t) -- rec.t itself -- and the lane either enters
+                // the instance's tree or moves on to index u + 1 within the same pass.
+                bool looking = phase == ST_CONTROL && ctl == CT_NEXT_INSTANCE;
+                for (uint32_t u = 0; u < sc.n_instances; ++u) {
+                    const bool mine = looking && inst == u;
+                    if (__ballot(mine) == 0ull) continue;
+                    const ConstInstance I = inst_base + u;
+                    float m[12];
+#pragma unroll
+                    for (int k = 0; k < 12; ++k) m[k] = I->inv[k];
+                    const V3 np = xf_point(m, ray.pos), nd = xf_vector(m, ray.dir);
+                    const DirRcp nr = make_dir_rcp(np, nd, sc.fast_div != 0u);
+                    const float blox = I->root.lox[0], bloy = I->root.loy[0], bloz = I->root.loz[0];
+                    const float bhix = I->root.hix[0], bhiy = I->root.hiy[0], bhiz = I->root.hiz[0];
+                    const SlabApprox sa = slab_approx(blox, bloy, bloz, bhix, bhiy, bhiz, np.x, np.y, np.z, nr.x, nr.y, nr.z);
+                    float dist = slab_dist(sa);
+                    const bool vague = slab_ambiguous(sa, rec.t);
+                    const bool amb = mine && (!nr.ok || vague);
+                    if (__ballot(amb) != 0ull) {
+                        const float4 lo4 = make_float4(blox, bloy, bloz, 0.0f), hi4 = make_float4(bhix, bhiy, bhiz, 0.0f);
+                        const bool out_of_range = mine && !nr.ok;
+                        if (__ballot(out_of_range) == 0ull) dist = hits_bounding_rcp(np, nd, nr, lo4, hi4);
+                        else dist = hits_bounding(np, nd, lo4, hi4);
+                    }
+                    const uint32_t a = I->root.a[0], b = I->root.b[0];
+                    const bool is_internal = b == kInternalTag, has_tris = a <= b;
+                    const bool hit_box = dist != RT_INF, within = !(dist > rec.t);
+                    const bool enter = mine && hit_box && within && (is_internal || has_tris);
+                    const bool enter_node = enter && is_internal, enter_leaf = enter && !is_internal;
+                    if (COUNT) rec.box_tests += mine ? 1u : 0u;
+                    dpx = enter ? f2{np.x, nd.x} : dpx;
+                    dpy = enter ? f2{np.y, nd.y} : dpy;
+                    dpz = enter ? f2{np.z, nd.z} : dpz;
+                    rcx = enter ? nr.x : rcx;
+                    rcy = enter ? nr.y : rcy;
+                    rcz = enter ? nr.z : rcz;
+                    rcp_ok = enter ? nr.ok : rcp_ok;
+                    cull = enter ? I->cull != 0u : cull;
+                    sp = enter ? 0u : sp;
+                    phase = enter_node ? (uint32_t)ST_DESC : enter_leaf ? (uint32_t)ST_LEAF : phase;
+                    cur = enter_node ? a << 1 : enter_leaf ? a : cur;
+                    tri_last = enter_leaf ? b : tri_last;
+                    next_off = enter_node ? sc.node_off + a * 64u : next_off;
+                    inst = (mine && !enter) ? u + 1u : inst;
+                    looking = looking && !enter;
+                }
+                if (looking) ctl = CT_SHADE;  // every instance has been visited
+                // (2)
+                if (phase == ST_CONTROL) {
+                    if (ctl == CT_SHADE) {
+                        // the rest of trace_ray, trace.rs:97-172
+                        const uint32_t idx = x + y * cam.W;
+                        if (seg == 0 && fr.hit_triangle) {
+                            fr.hit_triangle[idx] = rec.triangle_id;
+                            fr.hit_instance[idx] = rec.instance_id;
+                            fr.hit_t_bits[idx] = __float_as_uint(rec.t);
+                        }
+                        if (COUNT) {
+                            if (seg == 0 && fr.box_tests) {
+                                fr.box_tests[idx] = rec.box_tests;
+                                fr.triangle_tests[idx] = rec.triangle_tests;
+                            }
+                            n_box += rec.box_tests;
+                            n_internal += rec.internal_visits;
+                            n_tri += rec.triangle_tests;
+                        }
+                        int state = shade(sc, cam, rec, ray, seed, color);
+                        seg += 1;
+                        if (state == STATE_RAY && seg < cam.depth) {
+                            ctl = CT_START_SEGMENT;
+                        } else {
+                            if (state == STATE_RAY) color = v3(0.0f, 0.0f, 0.0f);  // never finished bouncing, trace.rs:204-205
+                            // shader/src/lib.rs:71-98 (the presented colour is derived from the accumulator by
+                            // present_kernel afterwards), then the event loop's bookkeeping, main.rs:147-148
+                            acc = accumulate_only(fwm, acc, color);
+                            n_paths += 1;
+                            frame += cam.frame_stride;
+                            fwm += 1.0f;
+                            frames_left -= 1u;
+                            ctl = CT_NEW_PATH;
+                            if (frames_left == 0u) {
+                                reinterpret_cast<float4*>(fr.acc)[idx] = acc;
+                                if (q.cost) atomicAdd(&q.cost[tile], seg);  // length of the pixel's last path
+                                ctl = CT_NEW_PIXEL;
+                            }
+                        }
+                    }
                     if (ctl == CT_NEW_PATH) {
                         // shader/src/lib.rs:57-69 and Ray::get_color, trace.rs:175-191
                         seed = cam.seed_mode ? get_seed(frame, x, y, 0.0f, 0.0f, 0.0f)
@@ -317,71 +410,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((COUNT |
                         n_rays += 1;
                         ctl = CT_NEXT_INSTANCE;
                     }
-                    if (inst < sc.n_instances) {
-                        next_off = sc.inst_off + inst * (uint32_t)sizeof(DevInstance);
-                        phase = ST_SETUP;
-                        break;
-                    }
-                    // every instance has been visited: the rest of trace_ray, trace.rs:97-172
-                    const uint32_t idx = x + y * cam.W;
-                    if (seg == 0 && fr.hit_triangle) {
-                        fr.hit_triangle[idx] = rec.triangle_id;
-                        fr.hit_instance[idx] = rec.instance_id;
-                        fr.hit_t_bits[idx] = __float_as_uint(rec.t);
-                    }
-                    if (COUNT) {
-                        if (seg == 0 && fr.box_tests) {
-                            fr.box_tests[idx] = rec.box_tests;
-                            fr.triangle_tests[idx] = rec.triangle_tests;
-                        }
-                        n_box += rec.box_tests;
-                        n_internal += rec.internal_visits;
-                        n_tri += rec.triangle_tests;
-                    }
-                    int state = shade(sc, cam, rec, ray, seed, color);
-                    seg += 1;
-                    if (state == STATE_RAY && seg < cam.depth) {
-                        ctl = CT_START_SEGMENT;
-                        continue;
-                    }
-                    if (state == STATE_RAY) color = v3(0.0f, 0.0f, 0.0f);  // never finished bouncing, trace.rs:204-205
-                    // shader/src/lib.rs:71-98 (the presented colour is derived from the accumulator by
-                    // present_kernel afterwards), then the event loop's bookkeeping, main.rs:147-148
-                    acc = accumulate_only(fwm, acc, color);
-                    n_paths += 1;
-                    frame += cam.frame_stride;
-                    fwm += 1.0f;
-                    frames_left -= 1u;
-                    if (frames_left == 0u) {
-                        reinterpret_cast<float4*>(fr.acc)[idx] = acc;
-                        if (q.cost) atomicAdd(&q.cost[tile], seg);  // length of the pixel's last path
-                        ctl = CT_NEW_PIXEL;
-                        break;
-                    }
-                    ctl = CT_NEW_PATH;
                 }
+                if (__ballot(phase == ST_CONTROL && ctl == CT_NEXT_INSTANCE) == 0ull) break;
             }
-        } else if (pick == 3) {
-            // trace.rs:76-94: the ray in the instance's object space; the clamp (EPS, record.t) is
-            // rec.t itself.  The item is the first line of the DevInstance: the inverse transform
-            // and the cull flag.  The next item is its second line, the root in the shape of a node.
-            const bool act = phase == ST_SETUP;
-            const float m[12] = {it0.x, it0.y, it0.z, it0.w, it1.x, it1.y, it1.z, it1.w, it2.x, it2.y, it2.z, it2.w};
-            const V3 np = xf_point(m, ray.pos), nd = xf_vector(m, ray.dir);
-            const DirRcp nr = make_dir_rcp(np, nd, sc.fast_div != 0u);
-            dpx = act ? f2{np.x, nd.x} : dpx;
-            dpy = act ? f2{np.y, nd.y} : dpy;
-            dpz = act ? f2{np.z, nd.z} : dpz;
-            rcx = act ? nr.x : rcx;
-            rcy = act ? nr.y : rcy;
-            rcz = act ? nr.z : rcz;
-            rcp_ok = act ? nr.ok : rcp_ok;
-            cull = act ? __float_as_uint(it3.x) != 0u : cull;
-            sp = act ? 0u : sp;
-            cur = act ? 0u : cur;  // child slot 0 of the root record
-            sp_counted = act ? false : sp_counted;
-            phase = act ? (uint32_t)ST_POP : phase;
-            next_off = act ? sc.inst_off + inst * (uint32_t)sizeof(DevInstance) + 64u : next_off;
         } else {
             bool finished;  // this lane has to pop (or its instance is done)
             const V3 lpos = v3(dpx.x, dpy.x, dpz.x), ldir = v3(dpx.y, dpy.y, dpz.y);
@@ -510,9 +541,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((COUNT |
                 const bool by_order = desc && first_is_1, by_slot = !desc && slot0;
                 const bool near0 = by_order || by_slot;
                 if (COUNT) {
-                    const bool first_test = act && !sp_counted;
+                    // a popped child was counted when its parent was visited
                     rec.internal_visits += desc ? 1u : 0u;
-                    rec.box_tests += desc ? 2u : first_test ? 1u : 0u;
+                    rec.box_tests += desc ? 2u : 0u;
                 }
                 // Three ways to the same decisions, chosen per wave.  The plain division is right
                 // for every lane; quotients through the cached reciprocal need the lane's operands
@@ -579,15 +610,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((COUNT |
             uint32_t ref = 0;
             if (pop) ref = stack[(sp - 1u) * kBlock];
             sp -= pop ? 1u : 0u;
-            sp_counted = pop ? true : sp_counted;
             inst += inst_end ? 1u : 0u;
-            const bool more = inst < sc.n_instances;
-            const bool to_setup = inst_end && more;
-            phase = pop ? (uint32_t)ST_POP : inst_end ? (more ? (uint32_t)ST_SETUP : (uint32_t)ST_CONTROL) : phase;
+            phase = pop ? (uint32_t)ST_POP : inst_end ? (uint32_t)ST_CONTROL : phase;
             cur = pop ? ref : cur;
-            ctl = inst_end ? (uint32_t)CT_NEXT_INSTANCE : ctl;  // shade, once every instance is done
-            next_off = pop ? sc.node_off + (ref >> 1) * 64u
-                           : to_setup ? sc.inst_off + inst * (uint32_t)sizeof(DevInstance) : next_off;
+            ctl = inst_end ? (uint32_t)CT_NEXT_INSTANCE : ctl;  // on to the next instance, if there is one
+            next_off = pop ? sc.node_off + (ref >> 1) * 64u : next_off;
         }
         if (next_off != kNoItem) {
             const f4* p = reinterpret_cast<const f4*>(sc.arena + next_off);
