@@ -126,15 +126,15 @@ int rt_read_counters(rt_ctx* ctx, uint32_t* box_tests, uint32_t* triangle_tests,
 int rt_get_stats(rt_ctx* ctx, rt_stats* out);
 /* Scheduling profile of the persistent kernel since the last rt_reset_stats
  * (maintained while RT_OPT_COUNTERS is on): per kind of step (0 control,
- * 1 box, 2 triangle, 3 instance set-up) the wave iterations that ran it and the lanes that took
+ * 1 box, 2 triangle) the wave iterations that ran it and the lanes that took
  * part, and the shader-clock cycles the waves spent in them (summed over waves;
  * a wave's cycles include the time its SIMD gave to other waves).
  * lanes / (64 * iterations) is the lane utilisation of that kind. */
 typedef struct rt_sched_stats {
-    uint64_t iterations[4];
-    uint64_t lanes[4];
-    uint64_t cycles[4];
-    uint64_t wait_cycles[4]; /* the part of `cycles` spent waiting for the step's prefetched item */
+    uint64_t iterations[3];
+    uint64_t lanes[3];
+    uint64_t cycles[3];
+    uint64_t wait_cycles[3]; /* the part of `cycles` spent waiting for the step's prefetched item */
 } rt_sched_stats;
 int rt_get_sched_stats(rt_ctx* ctx, rt_sched_stats* out);
 int rt_reset_stats(rt_ctx* ctx);

@@ -68,7 +68,7 @@ class Stats(C.Structure):
 
 
 class SchedStats(C.Structure):
-    _fields_ = [("iterations", C.c_uint64 * 4), ("lanes", C.c_uint64 * 4), ("cycles", C.c_uint64 * 4), ("wait_cycles", C.c_uint64 * 4)]
+    _fields_ = [("iterations", C.c_uint64 * 3), ("lanes", C.c_uint64 * 3), ("cycles", C.c_uint64 * 3), ("wait_cycles", C.c_uint64 * 3)]
 
 
 class BvhParams(C.Structure):

@@ -126,9 +126,9 @@ struct DevScene {
 struct DevStats {
     unsigned long long rays, box_tests, internal_visits, triangle_tests, paths;
     // scheduling profile of the persistent kernel (only with counters on):
-    // wave iterations that ran a control / box / triangle / instance set-up step,
+    // wave iterations that ran a control / box / triangle step,
     // the lanes that took part in them and the cycles they took
-    unsigned long long iters[4], lanes[4], cycles[4], wait_cycles[4];
+    unsigned long long iters[3], lanes[3], cycles[3], wait_cycles[3];
 };
 
 // Work queues of the persistent kernel: 8 ranges of 64-pixel items (8x8 tiles),
@@ -137,7 +137,7 @@ struct DevQueue {
     uint32_t* head;          // 8 counters, 32 words apart; zeroed before every launch
     uint32_t first_item[9];  // queue i covers items [first_item[i], first_item[i + 1])
     uint32_t tiles_x;        // 8x8 tiles per row of tiles
-    int w_ctl, w_box, w_leaf, w_setup;  // vote weights of the four kinds of step
+    int w_ctl, w_box, w_leaf;  // vote weights of the three kinds of step
     // Cost-aware order (both optional).  `order` permutes the tiles inside each queue's range:
     // position p of the queue stands for tile order[p].  `cost` receives, per tile, the path
     // lengths of this launch; order_tiles_kernel turns them into the next launch's order, dearest

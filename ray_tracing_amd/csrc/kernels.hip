@@ -156,18 +156,23 @@ __global__ __launch_bounds__(kBlock) void path_kernel(DevScene sc, DevCam cam, D
 // results are identical -- but scheduled for 64-wide waves:
 //
 //  * Each lane is a small state machine that owns ONE pending 64-byte item: an
-//    internal node (both children) or the first or second line of an instance.
-//    The load of the item is issued at the end of one step and consumed by the
-//    next, so a lane never has two dependent fetches in a step.  Items are
-//    named by 32-bit byte offsets into one arena.
-//  * A step is one of four kinds: CONTROL (generate a path, start a segment, or
-//    shade + accumulate after the last instance), SETUP (move the ray into the
-//    next instance's space), BOX (test the child box on top of the reference's
-//    stack, descend or pop) and LEAF (test the triangles of a leaf).  Per
-//    iteration the wave runs only the kind most of its lanes are waiting for;
-//    the others keep their item and wait.  No lane ever idles until its
-//    neighbours finish a subtree, an instance, a bounce or a frame.
-//  * The SETUP, BOX and LEAF steps are written without divergent branches: every
+//    internal node (both children).  The load of the item is issued at the end
+//    of one step and consumed by the next, so a traversing lane never has two
+//    dependent fetches in a step.  Items are named by 32-bit byte offsets into
+//    one arena.
+//  * A step is one of three kinds: CONTROL (generate a path, start a segment,
+//    walk the instance list -- ray into the instance's space, root box -- until
+//    an instance is entered, shade + accumulate after the last instance), BOX
+//    (test the child box on top of the reference's stack, descend or pop) and
+//    LEAF (test the triangles of a leaf).  Per iteration the wave runs only the
+//    kind most of its lanes are waiting for; the others keep their item and
+//    wait.  No lane ever idles until its neighbours finish a subtree, an
+//    instance, a bounce or a frame.
+//  * The instance walk of a CONTROL step runs over the instance indices in
+//    order, wave-uniformly, every lane joining in at its own index: instance
+//    records are scalar loads, and an instance whose root box is missed costs a
+//    lane no step of its own.
+//  * The BOX and LEAF steps are written without divergent branches: every
 //    lane computes, lanes that do not take part discard the results through
 //    selects.  The arithmetic of a BOX step covers both children of the node at
 //    once with packed 2 x f32 instructions.
@@ -208,8 +213,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((COUNT |
     const unsigned long long lanes_below = (1ull << lane) - 1ull;
 
     unsigned long long n_rays = 0, n_box = 0, n_internal = 0, n_tri = 0, n_paths = 0;
-    unsigned long long sched_iters[4] = {0, 0, 0, 0}, sched_lanes[4] = {0, 0, 0, 0}, sched_cycles[4] = {0, 0, 0, 0},
-                       sched_wait[4] = {0, 0, 0, 0};  // wave-uniform
+    unsigned long long sched_iters[3] = {0, 0, 0}, sched_lanes[3] = {0, 0, 0}, sched_cycles[3] = {0, 0, 0},
+                       sched_wait[3] = {0, 0, 0};  // wave-uniform
 
     const ConstInstance inst_base = (ConstInstance)(uintptr_t)sc.instances;
     uint32_t phase = n_frames > 0 ? ST_CONTROL : ST_DEAD;
@@ -350,6 +355,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((COUNT |
                     looking = looking && !enter;
                 }
                 if (looking) ctl = CT_SHADE;  // every instance has been visited
+                if (round == 1) break;  // whoever is through with its instances now is shaded in the next CONTROL step
                 // (2)
                 if (phase == ST_CONTROL) {
                     if (ctl == CT_SHADE) {
@@ -627,7 +633,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((COUNT |
     }
     flush_stats(fr, COUNT, lane, n_rays, n_paths, n_box, n_internal, n_tri);
     if (COUNT && lane == 0 && fr.stats) {
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < 3; ++k) {
             atomicAdd(&fr.stats->iters[k], sched_iters[k]);
             atomicAdd(&fr.stats->lanes[k], sched_lanes[k]);
             atomicAdd(&fr.stats->cycles[k], sched_cycles[k]);

@@ -52,7 +52,7 @@ struct rt_ctx {
     uint32_t order_sig[5] = {0, 0, 0, 0, 0};
     bool tile_order_enabled = true;
     int n_cus = 0;
-    int vote_w[4] = {2, 1, 3, 2};  // vote weights: control, box, triangle, instance set-up steps
+    int vote_w[3] = {3, 2, 6};  // vote weights: control, box, triangle steps
 
     // options
     int pipeline = 1;
@@ -226,7 +226,6 @@ int render(rt_ctx* c, const rt_cam_data& cam, uint32_t n_frames) {
         q.w_ctl = c->vote_w[0];
         q.w_box = c->vote_w[1];
         q.w_leaf = c->vote_w[2];
-        q.w_setup = c->vote_w[3];
         uint32_t* order_out = nullptr;
         if (c->tile_order_enabled) {
             const uint32_t n_tiles = persistent_tile_count(dc, rows);
@@ -298,12 +297,11 @@ int rt_create(int device, rt_ctx** out) {
     c->n_cus = prop.multiProcessorCount;
     if (std::getenv("RT_NO_TILE_ORDER")) c->tile_order_enabled = false;  // tuning knob
     if (const char* w = std::getenv("RT_VOTE_WEIGHTS")) {
-        int a = 1, b = 1, d = 1, s = 1;
-        if (std::sscanf(w, "%d,%d,%d,%d", &a, &b, &d, &s) == 4 && a > 0 && b > 0 && d > 0 && s > 0) {
+        int a = 1, b = 1, d = 1;
+        if (std::sscanf(w, "%d,%d,%d", &a, &b, &d) == 3 && a > 0 && b > 0 && d > 0) {
             c->vote_w[0] = a;
             c->vote_w[1] = b;
             c->vote_w[2] = d;
-            c->vote_w[3] = s;
         }
     }
     *out = c;
@@ -529,7 +527,7 @@ int rt_get_sched_stats(rt_ctx* c, rt_sched_stats* out) {
     RT_HIP(c, hipSetDevice(c->device));
     RT_HIP(c, hipMemcpyAsync(&s, c->d_stats, sizeof s, hipMemcpyDeviceToHost, c->stream));
     RT_HIP(c, hipStreamSynchronize(c->stream));
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < 3; ++k) {
         out->iterations[k] = s.iters[k];
         out->lanes[k] = s.lanes[k];
         out->cycles[k] = s.cycles[k];
