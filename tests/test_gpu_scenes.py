@@ -111,6 +111,41 @@ def ortho_like_cam(w, h, z=6.0, fov=60.0, depth=3):
     return S.make_cam(w, h, t, fov=fov, depth=depth)
 
 
+def test_several_hundred_instances_of_small_meshes():
+    """Every ray walks the whole instance list (trace.rs:76): 400 instances of two small meshes,
+    most of whose root boxes a given ray misses, some nested inside each other, plus one
+    instance whose root is a single leaf."""
+    rng = np.random.default_rng(11)
+    sv, sf = S.icosphere(1)
+    cv, cf = S.cube_mesh(inward=False)
+    def xf(scale_lo, scale_hi, spread):
+        axis, angle = "xyz"[int(rng.integers(0, 3))], float(rng.uniform(-3.1, 3.1))
+        return S.affine_from_srt([float(x) for x in rng.uniform(scale_lo, scale_hi, 3)], S.quat_from_rotation(axis, angle),
+                                 [float(x) for x in rng.uniform(-spread, spread, 3)])
+    b = S.SceneBuilder()
+    b.add_mesh(np.asarray(sv, F), np.asarray(sf, np.uint32), [xf(0.5, 2.0, 14.0) for _ in range(250)],
+               S.bvh_params(leaf_max=3, root_leaf_max=0, threads=1))
+    b.add_mesh(np.asarray(cv, F), np.asarray(cf, np.uint32), [xf(0.5, 6.0, 10.0) for _ in range(149)],
+               S.bvh_params(leaf_max=2, root_leaf_max=0, threads=1))
+    rv, rf = S.cube_mesh(inward=True)  # a room around everything, culled from outside; its root is a leaf
+    b.add_mesh(np.asarray(rv, F), np.asarray(rf, np.uint32), [xf(20.0, 25.0, 1.0)],
+               S.bvh_params(leaf_max=16, root_leaf_max=100, threads=1))
+    scene = b.build()
+    assert len(scene.instances) == 400
+    kinds = [RT_MAT_GENERIC, RT_MAT_NORMAL, RT_MAT_EMISSIVE]
+    materials = []
+    for i in range(400):
+        m = Material()
+        m.kind, m.backface_culling = kinds[i % 3], int(i % 2)
+        m.color[:] = [0.9, 0.8, 0.7] if m.kind != RT_MAT_EMISSIVE else [3.0, 3.0, 2.0]
+        m.ior, m.roughness = (1.5 if i % 6 == 0 else 0.0), 0.4
+        materials.append(m)
+    cam = S.make_cam(96, 64, S.look_at((0.0, 4.0, -24.0), (0.0, 0.0, 0.0)), fov=70.0, depth=6)
+    for pipeline in (1, 0):
+        g, ref = check_against_oracle(scene, cam, frames=2, materials=materials, pipeline=pipeline)
+    assert len(np.unique(ref.hit_instance[ref.hit_triangle != 0xFFFFFFFF])) > 30
+
+
 def test_hand_built_trees_with_edge_cases():
     # 1. two coplanar triangles sharing an edge, in two leaves (tie rules, hit.rs:94-100, 159)
     left = [(-2, -1, 0), (0, -1, 0), (0, 1, 0)]
