@@ -236,6 +236,12 @@ uint64_t rt_selftest_slab_filter(uint64_t n, uint64_t seed, uint64_t* n_clear);
  * cases that were called clear-cut. */
 uint64_t rt_selftest_tri_filter(uint64_t n, uint64_t seed, uint64_t* n_clear);
 
+/* Device self-test of the one hardware property the instance walk's root-box shortcut
+ * assumes: the approximate reciprocal instruction is within 1 unit in the last place of the
+ * correctly rounded reciprocal.  Checks every float d with 2^-24 <= |d| <= 2^24 on `device`
+ * and stores the largest error found, in units in the last place.  Must be <= 1. */
+int rt_selftest_rcp_device(int device, uint32_t* max_ulp_error);
+
 /* Image files, in place of the reference's copy of binding 8 into the swapchain
  * (vulkan.rs:1045-1101).  Both take a host buffer of width*height RGBA floats, as
  * rt_read_present / rt_read_acc fill it, row 0 at the top.

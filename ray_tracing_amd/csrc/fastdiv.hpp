@@ -87,6 +87,11 @@ struct SlabApprox {
 };
 
 constexpr float kSlabMargin = 4.76837158203125e-07f;  // 2^-21
+// The same shortcut with reciprocals from the hardware's approximate instruction (v_rcp_f32, at
+// most 1 ulp off: r within 2^-23 relative of 1/d) instead of correctly rounded ones: the bound
+// becomes |q - t| < (2^-23 + 2^-24 + 2^-24 + second order) |q| < 2^-21.9 |q|, so comparisons are
+// clear-cut beyond twice that; 2^-20 leaves the same factor of slack as above.
+constexpr float kSlabMarginApproxRcp = 9.5367431640625e-07f;  // 2^-20
 
 RT_HD SlabApprox slab_approx(float lox, float loy, float loz, float hix, float hiy, float hiz, float px, float py,
                              float pz, float rx, float ry, float rz) {
@@ -99,10 +104,10 @@ RT_HD SlabApprox slab_approx(float lox, float loy, float loz, float hix, float h
 }
 
 // Written so that a NaN anywhere (a NaN clamp) reads as ambiguous.
-RT_HD bool slab_ambiguous(SlabApprox s, float t_hi) {
+RT_HD bool slab_ambiguous(SlabApprox s, float t_hi, float margin = kSlabMargin) {
     float an = __builtin_fabsf(s.t_near), af = __builtin_fabsf(s.t_far);
-    bool clear_order = __builtin_fabsf(s.t_far - s.t_near) > kSlabMargin * (an + af);
-    bool clear_clamp = __builtin_fabsf(s.t_near - t_hi) > kSlabMargin * an;
+    bool clear_order = __builtin_fabsf(s.t_far - s.t_near) > margin * (an + af);
+    bool clear_clamp = __builtin_fabsf(s.t_near - t_hi) > margin * an;
     return !(clear_order && clear_clamp);
 }
 

@@ -319,38 +319,50 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((COUNT |
 #pragma unroll
                     for (int k = 0; k < 12; ++k) m[k] = I->inv[k];
                     const V3 np = xf_point(m, ray.pos), nd = xf_vector(m, ray.dir);
-                    const DirRcp nr = make_dir_rcp(np, nd, sc.fast_div != 0u);
+                    const bool in_range = dir_rcp_ok(np, nd, sc.fast_div != 0u);
                     const float blox = I->root.lox[0], bloy = I->root.loy[0], bloz = I->root.loz[0];
                     const float bhix = I->root.hix[0], bhiy = I->root.hiy[0], bhiz = I->root.hiz[0];
-                    const SlabApprox sa = slab_approx(blox, bloy, bloz, bhix, bhiy, bhiz, np.x, np.y, np.z, nr.x, nr.y, nr.z);
-                    float dist = slab_dist(sa);
-                    const bool vague = slab_ambiguous(sa, rec.t);
-                    const bool amb = mine && (!nr.ok || vague);
-                    if (__ballot(amb) != 0ull) {
-                        const float4 lo4 = make_float4(blox, bloy, bloz, 0.0f), hi4 = make_float4(bhix, bhiy, bhiz, 0.0f);
-                        const bool out_of_range = mine && !nr.ok;
-                        if (__ballot(out_of_range) == 0ull) dist = hits_bounding_rcp(np, nd, nr, lo4, hi4);
-                        else dist = hits_bounding(np, nd, lo4, hi4);
-                    }
                     const uint32_t a = I->root.a[0], b = I->root.b[0];
                     const bool is_internal = b == kInternalTag, has_tris = a <= b;
-                    const bool hit_box = dist != RT_INF, within = !(dist > rec.t);
-                    const bool enter = mine && hit_box && within && (is_internal || has_tris);
-                    const bool enter_node = enter && is_internal, enter_leaf = enter && !is_internal;
+                    // First from the hardware's approximate reciprocals (three instructions): most
+                    // lanes miss most root boxes, clearly.  Only when some lane hits one, or cannot
+                    // tell, are the correctly rounded reciprocals formed -- the traversal needs them
+                    // then anyway.
+                    const SlabApprox sa = slab_approx(blox, bloy, bloz, bhix, bhiy, bhiz, np.x, np.y, np.z,
+                                                      __builtin_amdgcn_rcpf(nd.x), __builtin_amdgcn_rcpf(nd.y),
+                                                      __builtin_amdgcn_rcpf(nd.z));
+                    const float dist_apx = slab_dist(sa);
+                    const bool vague = slab_ambiguous(sa, rec.t, kSlabMarginApproxRcp);
+                    const bool amb = mine && (!in_range || vague);
+                    const bool may_enter = amb || (mine && dist_apx != RT_INF && !(dist_apx > rec.t));
+                    bool enter = false;
+                    if (__ballot(may_enter) != 0ull) {
+                        const DirRcp nr = make_dir_rcp(np, nd, sc.fast_div != 0u);
+                        float dist = dist_apx;
+                        if (__ballot(amb) != 0ull) {
+                            const float4 lo4 = make_float4(blox, bloy, bloz, 0.0f), hi4 = make_float4(bhix, bhiy, bhiz, 0.0f);
+                            const bool out_of_range = mine && !in_range;
+                            if (__ballot(out_of_range) == 0ull) dist = hits_bounding_rcp(np, nd, nr, lo4, hi4);
+                            else dist = hits_bounding(np, nd, lo4, hi4);
+                        }
+                        const bool hit_box = dist != RT_INF, within = !(dist > rec.t);
+                        enter = mine && hit_box && within && (is_internal || has_tris);
+                        const bool enter_node = enter && is_internal, enter_leaf = enter && !is_internal;
+                        dpx = enter ? f2{np.x, nd.x} : dpx;
+                        dpy = enter ? f2{np.y, nd.y} : dpy;
+                        dpz = enter ? f2{np.z, nd.z} : dpz;
+                        rcx = enter ? nr.x : rcx;
+                        rcy = enter ? nr.y : rcy;
+                        rcz = enter ? nr.z : rcz;
+                        rcp_ok = enter ? nr.ok : rcp_ok;
+                        cull = enter ? I->cull != 0u : cull;
+                        sp = enter ? 0u : sp;
+                        phase = enter_node ? (uint32_t)ST_DESC : enter_leaf ? (uint32_t)ST_LEAF : phase;
+                        cur = enter_node ? a << 1 : enter_leaf ? a : cur;
+                        tri_last = enter_leaf ? b : tri_last;
+                        next_off = enter_node ? sc.node_off + a * 64u : next_off;
+                    }
                     if (COUNT) rec.box_tests += mine ? 1u : 0u;
-                    dpx = enter ? f2{np.x, nd.x} : dpx;
-                    dpy = enter ? f2{np.y, nd.y} : dpy;
-                    dpz = enter ? f2{np.z, nd.z} : dpz;
-                    rcx = enter ? nr.x : rcx;
-                    rcy = enter ? nr.y : rcy;
-                    rcz = enter ? nr.z : rcz;
-                    rcp_ok = enter ? nr.ok : rcp_ok;
-                    cull = enter ? I->cull != 0u : cull;
-                    sp = enter ? 0u : sp;
-                    phase = enter_node ? (uint32_t)ST_DESC : enter_leaf ? (uint32_t)ST_LEAF : phase;
-                    cur = enter_node ? a << 1 : enter_leaf ? a : cur;
-                    tri_last = enter_leaf ? b : tri_last;
-                    next_off = enter_node ? sc.node_off + a * 64u : next_off;
                     inst = (mine && !enter) ? u + 1u : inst;
                     looking = looking && !enter;
                 }

@@ -179,14 +179,17 @@ struct DirRcp {
     float x, y, z;
     bool ok;
 };
+RT_DEV bool dir_rcp_ok(V3 pos, V3 dir, bool scene_ok) {
+    // bitwise on purpose: six cheap tests, no branches
+    return (int(scene_ok) & int(div_den_ok(dir.x)) & int(div_den_ok(dir.y)) & int(div_den_ok(dir.z)) &
+            int(div_term_ok(pos.x)) & int(div_term_ok(pos.y)) & int(div_term_ok(pos.z))) != 0;
+}
 RT_DEV DirRcp make_dir_rcp(V3 pos, V3 dir, bool scene_ok) {
     DirRcp r;
     r.x = 1.0f / dir.x;
     r.y = 1.0f / dir.y;
     r.z = 1.0f / dir.z;
-    // bitwise on purpose: six cheap tests, no branches
-    r.ok = (int(scene_ok) & int(div_den_ok(dir.x)) & int(div_den_ok(dir.y)) & int(div_den_ok(dir.z)) &
-            int(div_term_ok(pos.x)) & int(div_term_ok(pos.y)) & int(div_term_ok(pos.z))) != 0;
+    r.ok = dir_rcp_ok(pos, dir, scene_ok);
     return r;
 }
 

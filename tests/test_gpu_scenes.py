@@ -452,3 +452,11 @@ def test_full_size_properties(c3):
         finally:
             app.destroy()
     assert_bits_equal(combined, a["acc"], "8-way tile partition")
+
+
+def test_hardware_reciprocal_is_within_one_ulp_over_the_divisor_range():
+    """The instance walk first decides root boxes from v_rcp_f32 reciprocals with a margin
+    derived from a 1-ulp bound; this checks that bound for every float in the range."""
+    worst = C.c_uint32(99)
+    assert L.load().rt_selftest_rcp_device(0, C.byref(worst)) == 0
+    assert worst.value <= 1
