@@ -207,6 +207,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((COUNT |
                                                                  DevQueue q, uint32_t n_frames) {
     __shared__ uint32_t s_stack[STACK_N * kBlock];
     __shared__ uint32_t s_tmp[kBlock];  // 64 words per wave: who works for whom in a LEAF step
+    __shared__ unsigned long long s_best[kBlock];  // per lane: what an owner keeps of a LEAF step's results
 
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t* const stack = &s_stack[threadIdx.x];
@@ -504,19 +505,42 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((COUNT |
                         t = triangle_ray_intersect(fp[0], fp[1], fp[2], fp[3].x, wpos, wdir, kEps, RT_INF, w_cull);
                     }
                 }
-                // every owner goes through its own results in order
+                // What an owner keeps of its results is what the sequential loop would keep: a
+                // candidate (a finite distance) is accepted when it is not beyond the best so far,
+                // so the survivor is the smallest candidate that is not beyond the clamp, the last
+                // one among equals.  With no NaN among the results that is a minimum over
+                // (distance, position from the end): the workers fold their candidates into the
+                // owner's LDS slot with one 64-bit atomic minimum each (distances are >= EPS > 0,
+                // so their bit patterns order like the numbers).  A NaN clamp accepts everything,
+                // as `t > NaN` is false.  A NaN result (a zero-area triangle) makes what follows
+                // it depend on the order, so such a wave walks through the results one by one.
                 float best = rec.t;
                 uint32_t best_k = 0xFFFFFFFFu;
-                for (uint32_t k0 = 0; __ballot(k0 < n_proc) != 0ull; k0 += 4u) {
-                    float tk[4];  // four results on their way at a time
+                const bool t_nan = t != t;
+                if (__ballot(t_nan) == 0ull) {
+                    const float o_clamp = __shfl(rec.t, (int)o, 64);
+                    unsigned long long* const slot = &s_best[threadIdx.x & ~63u];
+                    slot[lane] = ~0ull;
+                    asm volatile("" ::: "memory");
+                    const bool cand = work && !is_inf_bits(t) && !(t > o_clamp);
+                    if (cand) atomicMin(&slot[o], ((unsigned long long)__float_as_uint(t) << 32) | (0xFFFFFFFFu - kw));
+                    asm volatile("" ::: "memory");
+                    const unsigned long long kept = slot[lane];
+                    const bool any = owner && kept != ~0ull;
+                    best = any ? __uint_as_float((uint32_t)(kept >> 32)) : best;
+                    best_k = any ? 0xFFFFFFFFu - (uint32_t)kept : best_k;
+                } else {
+                    for (uint32_t k0 = 0; __ballot(k0 < n_proc) != 0ull; k0 += 4u) {
+                        float tk[4];  // four results on their way at a time
 #pragma unroll
-                    for (uint32_t j = 0; j < 4u; ++j) tk[j] = __shfl(t, (int)((excl + k0 + j) & 63u), 64);
+                        for (uint32_t j = 0; j < 4u; ++j) tk[j] = __shfl(t, (int)((excl + k0 + j) & 63u), 64);
 #pragma unroll
-                    for (uint32_t j = 0; j < 4u; ++j) {
-                        const bool mine = k0 + j < n_proc, finite = !is_inf_bits(tk[j]), farther = tk[j] > best;
-                        const bool keep = mine && finite && !farther;
-                        best = keep ? tk[j] : best;
-                        best_k = keep ? k0 + j : best_k;
+                        for (uint32_t j = 0; j < 4u; ++j) {
+                            const bool mine = k0 + j < n_proc, finite = !is_inf_bits(tk[j]), farther = tk[j] > best;
+                            const bool keep = mine && finite && !farther;
+                            best = keep ? tk[j] : best;
+                            best_k = keep ? k0 + j : best_k;
+                        }
                     }
                 }
                 const bool hit = best_k != 0xFFFFFFFFu;
