@@ -242,6 +242,13 @@ uint64_t rt_selftest_tri_filter(uint64_t n, uint64_t seed, uint64_t* n_clear);
  * and stores the largest error found, in units in the last place.  Must be <= 1. */
 int rt_selftest_rcp_device(int device, uint32_t* max_ulp_error);
 
+/* Device self-test of the short square root, reciprocal and n/65535 sequences the kernels use
+ * in place of the compiler's general expansions: every operand of their ranges (all floats in
+ * [2^-100, 2^100], both signs for the reciprocal; n = 0..65535) is evaluated on `device` both
+ * ways.  mismatches[0..2] receive how many square roots, reciprocals and quotients differ in
+ * any bit.  All three must be 0. */
+int rt_selftest_fastmath_device(int device, uint64_t mismatches[3]);
+
 /* Image files, in place of the reference's copy of binding 8 into the swapchain
  * (vulkan.rs:1045-1101).  Both take a host buffer of width*height RGBA floats, as
  * rt_read_present / rt_read_acc fill it, row 0 at the top.

@@ -110,6 +110,7 @@ SIGNATURES = {
     "rt_render_frame": (_i32, [_vp, _P(CamData)]),
     "rt_render_frames": (_i32, [_vp, _P(CamData), _u32]),
     "rt_synchronize": (_i32, [_vp]),
+    "rt_selftest_fastmath_device": (_i32, [C.c_int, _P(C.c_uint64)]),
     "rt_selftest_rcp_device": (_i32, [C.c_int, _P(C.c_uint32)]),
     "rt_save_png": (_i32, [C.c_char_p, _vp, C.c_uint32, C.c_uint32]),
     "rt_save_exr": (_i32, [C.c_char_p, _vp, C.c_uint32, C.c_uint32, C.c_float]),

@@ -16,6 +16,7 @@
 
 #include "device_types.hpp"
 #include "fastdiv.hpp"
+#include "fastexact.hpp"
 
 #pragma clang fp contract(off)
 
@@ -42,9 +43,23 @@ RT_DEV float dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 RT_DEV V3 cross(V3 a, V3 b) {
     return V3{a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y};
 }
-RT_DEV float length(V3 a) { return __builtin_sqrtf(dot(a, a)); }
+// sqrt and 1/x, correctly rounded: the short forms of fastexact.hpp when every active lane's
+// operand is in their checked range, the plain operators for the whole wave otherwise
+RT_DEV float exact_sqrt(float x) {
+    if (__ballot(!fx_ok(x)) == 0ull) return fx_sqrt(x);
+    return __builtin_sqrtf(x);
+}
+RT_DEV float exact_rcp(float x) {
+    if (__ballot(!fx_ok(fabsf(x))) == 0ull) return fx_rcp(x);
+    return 1.0f / x;
+}
+RT_DEV float length(V3 a) { return exact_sqrt(dot(a, a)); }
+// glam Vec3::normalize: self * length().recip()
 RT_DEV V3 normalize(V3 a) {
-    float r = 1.0f / length(a);
+    const float l2 = dot(a, a);
+    float r;
+    if (__ballot(!fx_ok(l2)) == 0ull) r = fx_rcp(fx_sqrt(l2));  // the root of an in-range number is in range
+    else r = 1.0f / __builtin_sqrtf(l2);
     return a * r;
 }
 RT_DEV V3 lerp(V3 a, V3 b, float s) { return a * (1.0f - s) + b * s; }
@@ -78,14 +93,14 @@ RT_DEV float rand_float(uint32_t& seed, float lo, float hi) {
     x ^= x >> 17;
     x ^= x << 5;
     seed = x;
-    return (float)(x & 65535u) / 65535.0f * (hi - lo) + lo;
+    return fx_div_65535((float)(x & 65535u)) * (hi - lo) + lo;
 }
 
 // shared/src/lib.rs:47-57
 RT_DEV float acos_approx(float v) {
     float x = fabsf(v);
     float res = -0.155972f * x + 1.56467f;
-    res *= __builtin_sqrtf(1.0f - x);
+    res *= exact_sqrt(1.0f - x);
     return v >= 0.0f ? res : kPi - res;
 }
 
@@ -186,10 +201,16 @@ RT_DEV bool dir_rcp_ok(V3 pos, V3 dir, bool scene_ok) {
 }
 RT_DEV DirRcp make_dir_rcp(V3 pos, V3 dir, bool scene_ok) {
     DirRcp r;
-    r.x = 1.0f / dir.x;
-    r.y = 1.0f / dir.y;
-    r.z = 1.0f / dir.z;
     r.ok = dir_rcp_ok(pos, dir, scene_ok);
+    if (__ballot(!r.ok) == 0ull) {  // the divisor range of fastdiv.hpp lies inside fastexact.hpp's
+        r.x = fx_rcp(dir.x);
+        r.y = fx_rcp(dir.y);
+        r.z = fx_rcp(dir.z);
+    } else {
+        r.x = 1.0f / dir.x;
+        r.y = 1.0f / dir.y;
+        r.z = 1.0f / dir.z;
+    }
     return r;
 }
 
@@ -353,7 +374,7 @@ RT_DEV V3 generic_reflect(V3 in_dir, V3 normal, float roughness, uint32_t& seed)
 RT_DEV V3 glam_refract(V3 i, V3 n, float eta) {
     float n_dot_i = dot(n, i);
     float k = 1.0f - eta * eta * (1.0f - n_dot_i * n_dot_i);
-    if (k >= 0.0f) return i * eta - n * (eta * n_dot_i + __builtin_sqrtf(k));
+    if (k >= 0.0f) return i * eta - n * (eta * n_dot_i + exact_sqrt(k));
     return v3(0.0f, 0.0f, 0.0f);
 }
 
@@ -367,7 +388,7 @@ RT_DEV float powi5(float x) {
 RT_DEV int generic_bxdf(const DevInstance& m, V3& color, Ray& ray, V3 normal, float t, uint32_t& seed) {
     Ray in_ray = ray;
     float cos_theta = dot(in_ray.dir, normal);
-    float sin_theta = __builtin_sqrtf(1.0f - cos_theta * cos_theta);
+    float sin_theta = exact_sqrt(1.0f - cos_theta * cos_theta);
     V3 hit_pos = in_ray.pos + in_ray.dir * t;
 
     if (m.specular > 0.0f) {
@@ -429,7 +450,7 @@ RT_DEV int emissive_bxdf(const DevInstance& m, V3& color, Ray& ray, V3 normal, f
     Ray in_ray = ray;
     V3 ray_reversed = -normalize(in_ray.dir);
     float dot_product = fabsf(dot(ray_reversed, normal));
-    V3 stop = ld3(m.color) * __builtin_sqrtf(dot_product);
+    V3 stop = ld3(m.color) * exact_sqrt(dot_product);
     ray.pos = in_ray.pos + in_ray.dir * t;
     ray.dir = v3(0.0f, 0.0f, 0.0f);
     color = color * stop;

@@ -460,3 +460,11 @@ def test_hardware_reciprocal_is_within_one_ulp_over_the_divisor_range():
     worst = C.c_uint32(99)
     assert L.load().rt_selftest_rcp_device(0, C.byref(worst)) == 0
     assert worst.value <= 1
+
+
+def test_short_sqrt_reciprocal_and_rand_quotient_are_correctly_rounded_for_every_operand():
+    """fastexact.hpp: compared on the device with the compiler's IEEE results over the whole
+    range in which the kernels use them."""
+    bad = (C.c_uint64 * 3)(9, 9, 9)
+    assert L.load().rt_selftest_fastmath_device(0, bad) == 0
+    assert list(bad) == [0, 0, 0]
