@@ -95,6 +95,11 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene_info* info,
                     const rt_bvh* bvh, size_t n_bvh);
 /* Per-instance materials (extension, see rt_abi.h).  n must equal the number
  * of instances.  NULL / 0 restores the reference's constants. */
+/* New transforms (and object ids) for the instances of the uploaded scene: what the reference
+ * gets from refilling its instance buffer before every frame (vulkan.rs:238-353), at the cost of
+ * one small copy instead of a scene upload.  n must equal the uploaded instance count; materials
+ * stay as they are.  Waits for frames in flight on the context's stream. */
+int rt_update_instances(rt_ctx* ctx, const rt_instance* instances, size_t n);
 int rt_set_materials(rt_ctx* ctx, const rt_material* materials, size_t n);
 void rt_default_material(uint32_t instance_id, rt_material* out);
 

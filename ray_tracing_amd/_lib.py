@@ -105,6 +105,7 @@ SIGNATURES = {
     "rt_set_option": (_i32, [_vp, _i32, C.c_int64]),
     "rt_upload_scene": (_i32, [_vp, _P(SceneInfo), _vp, _sz, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _sz]),
     "rt_set_materials": (_i32, [_vp, _vp, _sz]),
+    "rt_update_instances": (_i32, [_vp, _vp, _sz]),
     "rt_default_material": (None, [_u32, _P(Material)]),
     "rt_set_rows": (_i32, [_vp, _u32, _u32, _u32]),
     "rt_render_frame": (_i32, [_vp, _P(CamData)]),

@@ -68,6 +68,12 @@ class App:
         if scene.materials is not None:
             self.set_materials(scene.materials)
 
+    def update_instances(self, instances):
+        """New transforms for the uploaded scene's instances (an INSTANCE_DT array of the same
+        length): the per-frame refill of the instance buffer, vulkan.rs:238-353."""
+        instances = np.ascontiguousarray(instances)
+        self._check(self._lib.rt_update_instances(self._ctx, _ptr(instances), len(instances)))
+
     def set_materials(self, materials):
         if materials is None:
             self._check(self._lib.rt_set_materials(self._ctx, None, 0))

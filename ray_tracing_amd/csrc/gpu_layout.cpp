@@ -87,6 +87,14 @@ bool make_child(const rt_bvh* bvh, size_t n_bvh, size_t n_triangles, const std::
 
 }  // namespace
 
+void set_instance_transform(DevInstance& di, const rt_instance& inst, const std::vector<DevObject>& objects) {
+    rt_affine3a inv = affine_inverse(inst.transform);  // trace.rs:87, hoisted
+    pack_affine(inv, di.inv);
+    pack_affine(inst.transform, di.fwd);
+    di.object_id = inst.object_id;
+    di.root = objects[inst.object_id].root;
+}
+
 bool build_gpu_scene(const rt_scene_info& info, const rt_vertex* vertices, size_t n_vertices, const rt_tri* triangles,
                      size_t n_triangles, const rt_object* objects, size_t n_objects, const rt_instance* instances,
                      size_t n_instances, const rt_bvh* bvh, size_t n_bvh, GpuScene& out, std::string& err) {
@@ -174,11 +182,7 @@ bool build_gpu_scene(const rt_scene_info& info, const rt_vertex* vertices, size_
         }
         DevInstance& di = out.instances[i];
         std::memset(&di, 0, sizeof di);
-        rt_affine3a inv = affine_inverse(instances[i].transform);  // trace.rs:87, hoisted
-        pack_affine(inv, di.inv);
-        pack_affine(instances[i].transform, di.fwd);
-        di.object_id = instances[i].object_id;
-        di.root = out.objects[di.object_id].root;
+        set_instance_transform(di, instances[i], out.objects);
         rt_material m;
         default_material(uint32_t(i), m);
         apply_material(di, m);

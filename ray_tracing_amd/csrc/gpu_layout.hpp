@@ -30,6 +30,9 @@ bool build_gpu_scene(const rt_scene_info& info, const rt_vertex* vertices, size_
                      size_t n_instances, const rt_bvh* bvh, size_t n_bvh, GpuScene& out, std::string& err);
 
 void apply_material(DevInstance& inst, const rt_material& m);
+// The transform part of a DevInstance (inverse, forward, object id, copy of the object's root
+// record) from an rt_instance; the material fields are left alone.
+void set_instance_transform(DevInstance& di, const rt_instance& inst, const std::vector<DevObject>& objects);
 void default_material(uint32_t instance_id, rt_material& m);
 
 }  // namespace rt

@@ -28,6 +28,7 @@ struct rt_ctx {
     DevTri* d_tris = nullptr;
     DevObject* d_objects = nullptr;
     std::vector<DevInstance> h_instances;
+    std::vector<DevObject> h_objects;
     uint32_t n_instances = 0;
     uint32_t max_depth = 0;
     bool fast_div = false;
@@ -389,10 +390,26 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_info* info, const rt_vertex* verti
     RT_HIP(c, hipMemcpy(c->d_arena + c->inst_off, g.instances.data(), g.instances.size() * sizeof(DevInstance),
                         hipMemcpyHostToDevice));
     c->h_instances = g.instances;
+    c->h_objects = g.objects;
     c->n_instances = (uint32_t)g.instances.size();
     c->max_depth = g.max_depth;
     c->fast_div = g.fast_div && std::getenv("RT_NO_FAST_DIV") == nullptr;
     c->have_scene = true;
+    return RT_OK;
+}
+
+int rt_update_instances(rt_ctx* c, const rt_instance* instances, size_t n) {
+    if (!c) return RT_ERR_INVALID;
+    if (!c->have_scene) return fail(c, RT_ERR_NO_SCENE, "rt_upload_scene has not been called");
+    if (!instances || n != c->n_instances) return fail(c, RT_ERR_INVALID, "the number of instances is fixed by rt_upload_scene");
+    for (size_t i = 0; i < n; ++i)
+        if (instances[i].object_id >= c->h_objects.size())
+            return fail(c, RT_ERR_INVALID, "instance " + std::to_string(i) + " references an object out of range");
+    for (size_t i = 0; i < n; ++i) set_instance_transform(c->h_instances[i], instances[i], c->h_objects);
+    RT_HIP(c, hipSetDevice(c->device));
+    RT_HIP(c, hipStreamSynchronize(c->stream));  // frames in flight still read the old records
+    RT_HIP(c, hipMemcpy(c->d_arena + c->inst_off, c->h_instances.data(), c->h_instances.size() * sizeof(DevInstance),
+                        hipMemcpyHostToDevice));
     return RT_OK;
 }
 

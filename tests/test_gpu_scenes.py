@@ -468,3 +468,33 @@ def test_short_sqrt_reciprocal_and_rand_quotient_are_correctly_rounded_for_every
     bad = (C.c_uint64 * 3)(9, 9, 9)
     assert L.load().rt_selftest_fastmath_device(0, bad) == 0
     assert list(bad) == [0, 0, 0]
+
+
+def test_moving_instances_between_frames_equals_uploading_the_moved_scene():
+    """rt_update_instances: the reference refills its instance buffer before every frame
+    (vulkan.rs:238-353); here only the instance records are rewritten."""
+    scene, cam = default_scene(96, 54)
+    moved = scene.instances.copy()
+    t = S.affine_from_srt((4.0, 6.0, 4.0), S.quat_from_rotation("z", 0.6), (3.0, -1.0, 2.0))
+    moved["transform"][0] = np.frombuffer(bytes(t), F)
+    moved["object_id"][[1, 2]] = moved["object_id"][[2, 1]]  # instances 1 and 2 swap their meshes
+    moved_scene = S.Scene(scene.info, scene.vertices, scene.triangles, scene.objects, moved, scene.bvh)
+    ref = O.OracleRenderer(moved_scene, cam, trig=O.TRIG_DET).render(2)
+    with App.create(copy_cam(cam), scene) as app:
+        app.set_option(RT_OPT_PROBE_HITS, 1)
+        app.render_frames(3)          # some frames of the original scene first
+        app.update_instances(moved)
+        app.cam_data = copy_cam(cam)
+        app.clear_acc()
+        app.render_frames(2)
+        app.synchronize()
+        assert_bits_equal(app.read_acc().reshape(-1, 4), ref.acc.reshape(-1, 4), "accumulator after the move")
+        tri, inst, tb = app.read_hits()
+        assert_bits_equal(tri, ref.hit_triangle, "triangle_id")
+        assert_bits_equal(inst, ref.hit_instance, "instance_id")
+        with pytest.raises(RtError):
+            app.update_instances(moved[:2])
+        bad = moved.copy()
+        bad["object_id"][0] = 99
+        with pytest.raises(RtError):
+            app.update_instances(bad)
