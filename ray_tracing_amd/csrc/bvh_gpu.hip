@@ -56,17 +56,6 @@ __global__ void scene_bounds(const rt_vertex* v, const rt_tri* t, uint32_t n, fl
     }
 }
 
-// spreads the low 21 bits of x so that two zero bits separate consecutive bits
-__device__ __forceinline__ uint64_t spread3(uint32_t x) {
-    uint64_t v = x & 0x1FFFFFu;
-    v = (v | v << 32) & 0x1F00000000FFFFull;
-    v = (v | v << 16) & 0x1F0000FF0000FFull;
-    v = (v | v << 8) & 0x100F00F00F00F00Full;
-    v = (v | v << 4) & 0x10C30C30C30C30C3ull;
-    v = (v | v << 2) & 0x1249249249249249ull;
-    return v;
-}
-
 __global__ void morton_codes(const rt_vertex* v, const rt_tri* t, uint32_t n, const float* bounds, uint64_t* keys,
                              uint32_t* order) {
     uint32_t i = blockIdx.x * kThreads + threadIdx.x;
@@ -80,7 +69,21 @@ __global__ void morton_codes(const rt_vertex* v, const rt_tri* t, uint32_t n, co
         u = u < 0.0f ? 0.0f : (u > 1.0f ? 1.0f : u);  // also maps NaN to 0
         q[k] = (uint32_t)(u * 2097151.0f);
     }
-    keys[i] = spread3(q[0]) << 2 | spread3(q[1]) << 1 | spread3(q[2]);
+    // The 63 key bits, most significant first, always come from the axis along which the current
+    // cell is longest (each bit halves the cell along its axis), not from x, y, z in turn: a flat
+    // or elongated scene is then not split along its short axes until the cells are about cubic.
+    float e[3] = {bounds[3] - bounds[0], bounds[4] - bounds[1], bounds[5] - bounds[2]};
+    int used[3] = {0, 0, 0};
+    uint64_t key = 0;
+    for (int b = 0; b < 63; ++b) {
+        int a = -1;
+        for (int k = 0; k < 3; ++k)
+            if (used[k] < 21 && (a < 0 || e[k] > e[a])) a = k;
+        key = key << 1 | ((q[a] >> (20 - used[a])) & 1u);
+        used[a] += 1;
+        e[a] *= 0.5f;
+    }
+    keys[i] = key;
     order[i] = i;
 }
 
