@@ -3,6 +3,7 @@ instance transforms, random per-instance materials, random cameras, random BVH b
 parameters) rendered by both GPU kernels and by the CPU oracle.  Everything must agree word
 for word: hit buffers, the reference's debug counters, accumulators, run totals."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -141,3 +142,13 @@ def test_random_scene_with_every_material_kind_matches_the_oracle(seed):
     big = seed % 4 == 3
     w, h = (int(rng.integers(40, 100)), int(rng.integers(30, 70))) if big else (int(rng.integers(5, 70)), int(rng.integers(5, 50)))
     compare(*random_scene(rng, w, h, big=big, kinds=ALL_KINDS))
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("RT_FUZZ_EXTRA", "0"))))
+def test_extra_random_scenes_on_request(seed):
+    """A soak run: RT_FUZZ_EXTRA=n adds n more scenes (all material kinds, every fourth one large)."""
+    rng = np.random.default_rng(20000 + seed)
+    big = seed % 4 == 3
+    w, h = (int(rng.integers(40, 100)), int(rng.integers(30, 70))) if big else (int(rng.integers(5, 70)), int(rng.integers(5, 50)))
+    unit = float(F(2.0) ** int(rng.choice([0, 0, 0, -30, -12, 12, 26, 30]))) if big else 1.0
+    compare(*random_scene(rng, w, h, big=big, unit=unit, kinds=ALL_KINDS))
