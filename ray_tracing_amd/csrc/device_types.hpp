@@ -110,15 +110,17 @@ struct DevRows {
 };
 
 // Nodes, triangle test records and instances live in ONE allocation (the
-// arena), so that the persistent kernel can name any item by a 32-bit byte
-// offset from one base address.  tris and objects are separate.
+// arena), so that the persistent kernel can name any item by a 32-bit offset
+// from one base address: a byte offset while the arena is below 4 GiB, a
+// record number (64-byte units) above that.  tris and objects are separate.
 struct DevScene {
     const DevNode* nodes;          // = arena + node_off
     const DevTri* tris;
     const DevObject* objects;
     const DevInstance* instances;  // = arena + inst_off
     const char* arena;
-    uint32_t node_off, tri_test_off, inst_off;  // byte offsets into the arena
+    uint32_t node_off, tri_test_off, inst_off;  // byte offsets into the arena (valid while the arena is below 4 GiB)
+    uint32_t node_unit, tri_test_unit;          // the same offsets in 64-byte records (any arena below 256 GiB)
     uint32_t n_instances;
     uint32_t fast_div;  // every box coordinate is 0 or has 2^-24 <= |b| <= 2^24 (see fastdiv.hpp)
 };

@@ -202,7 +202,9 @@ __device__ __forceinline__ f2 vmax(f2 a, f2 b) { return __builtin_elementwise_ma
 
 // The fast variant is held to 128 registers (4 waves per SIMD); the counting variant, which
 // carries the counters and the scheduling profile as well, is left alone.
-template <int STACK_N, bool COUNT>
+// BIG: items are named by record number instead of byte offset (arenas of 4 GiB and more); the
+// address of an item then takes 64-bit arithmetic, two or three more instructions per fetch.
+template <int STACK_N, bool COUNT, bool BIG>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((COUNT || STACK_N > 32) ? 1 : 4))) void path_kernel_persistent(DevScene sc, DevCam cam, DevRows rows, DevFrame fr,
                                                                  DevQueue q, uint32_t n_frames) {
     __shared__ uint32_t s_stack[STACK_N * kBlock];
@@ -217,6 +219,15 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((COUNT |
     unsigned long long sched_iters[3] = {0, 0, 0}, sched_lanes[3] = {0, 0, 0}, sched_cycles[3] = {0, 0, 0},
                        sched_wait[3] = {0, 0, 0};  // wave-uniform
 
+    // what names node record `a` / where a named item and a triangle's test record live
+    auto node_item = [&](uint32_t a) -> uint32_t { return BIG ? sc.node_unit + a : sc.node_off + a * 64u; };
+    auto item_ptr = [&](uint32_t item) -> const f4* {
+        return reinterpret_cast<const f4*>(BIG ? sc.arena + ((unsigned long long)item << 6) : sc.arena + item);
+    };
+    auto tri_test_ptr = [&](uint32_t tri) -> const f4* {
+        return reinterpret_cast<const f4*>(BIG ? sc.arena + ((unsigned long long)(sc.tri_test_unit + tri) << 6)
+                                               : sc.arena + (sc.tri_test_off + tri * 64u));
+    };
     const ConstInstance inst_base = (ConstInstance)(uintptr_t)sc.instances;
     uint32_t phase = n_frames > 0 ? ST_CONTROL : ST_DEAD;
     uint32_t ctl = CT_NEW_PIXEL;
@@ -361,7 +372,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((COUNT |
                         phase = enter_node ? (uint32_t)ST_DESC : enter_leaf ? (uint32_t)ST_LEAF : phase;
                         cur = enter_node ? a << 1 : enter_leaf ? a : cur;
                         tri_last = enter_leaf ? b : tri_last;
-                        next_off = enter_node ? sc.node_off + a * 64u : next_off;
+                        next_off = enter_node ? node_item(a) : next_off;
                     }
                     if (COUNT) rec.box_tests += mine ? 1u : 0u;
                     inst = (mine && !enter) ? u + 1u : inst;
@@ -472,7 +483,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((COUNT |
                 const uint32_t tri = (uint32_t)__shfl((int)cur, (int)o, 64) + kw;
                 f4 b0 = {0.0f, 0.0f, 0.0f, 0.0f}, b1 = b0, b2 = b0, b3 = b0;
                 if (work) {
-                    const f4* p = reinterpret_cast<const f4*>(sc.arena + (sc.tri_test_off + tri * 64u));
+                    const f4* p = tri_test_ptr(tri);
                     b0 = p[0];
                     b1 = p[1];
                     b2 = p[2];
@@ -643,7 +654,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((COUNT |
                 phase = internal ? (uint32_t)ST_DESC : leaf ? (uint32_t)ST_LEAF : phase;
                 cur = internal ? a << 1 : leaf ? a : cur;
                 tri_last = leaf ? b : tri_last;
-                next_off = internal ? sc.node_off + a * 64u : next_off;  // a leaf's triangles are fetched by the LEAF step
+                next_off = internal ? node_item(a) : next_off;  // a leaf's triangles are fetched by the LEAF step
             }
             // a lane that is through with its node or leaf: pop, or this instance is done (trace.rs:76)
             const bool empty = sp == 0u;
@@ -656,10 +667,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((COUNT |
             phase = pop ? (uint32_t)ST_POP : inst_end ? (uint32_t)ST_CONTROL : phase;
             cur = pop ? ref : cur;
             ctl = inst_end ? (uint32_t)CT_NEXT_INSTANCE : ctl;  // on to the next instance, if there is one
-            next_off = pop ? sc.node_off + (ref >> 1) * 64u : next_off;
+            next_off = pop ? node_item(ref >> 1) : next_off;
         }
         if (next_off != kNoItem) {
-            const f4* p = reinterpret_cast<const f4*>(sc.arena + next_off);
+            const f4* p = item_ptr(next_off);
             it0 = p[0];
             it1 = p[1];
             it2 = p[2];
@@ -738,7 +749,7 @@ hipError_t launch_path_kernel(const DevScene& sc, const DevCam& cam, const DevRo
 
 hipError_t launch_persistent_kernel(const DevScene& sc, const DevCam& cam, const DevRows& rows, const DevFrame& fr,
                                     DevQueue q, uint32_t* order_out, uint32_t n_frames, uint32_t stack_needed,
-                                    bool count, uint32_t n_blocks, hipStream_t stream) {
+                                    bool count, bool big, uint32_t n_blocks, hipStream_t stream) {
     // 8x8-pixel tiles of this context's rows, split into 8 contiguous ranges
     q.tiles_x = (cam.W + kPT - 1u) / kPT;
     const uint32_t tiles_y = (rows.local_rows + kPT - 1u) / kPT;
@@ -749,15 +760,20 @@ hipError_t launch_persistent_kernel(const DevScene& sc, const DevCam& cam, const
     if (e != hipSuccess) return e;
     if (q.cost && (e = hipMemsetAsync(q.cost, 0, (size_t)n_tiles * sizeof(uint32_t), stream)) != hipSuccess) return e;
     dim3 grid(n_blocks), block(kBlock);
-#define RT_LAUNCH(N, C) \
-    hipLaunchKernelGGL((path_kernel_persistent<N, C>), grid, block, 0, stream, sc, cam, rows, fr, q, n_frames)
+#define RT_LAUNCH(N, C, B) \
+    hipLaunchKernelGGL((path_kernel_persistent<N, C, B>), grid, block, 0, stream, sc, cam, rows, fr, q, n_frames)
+#define RT_LAUNCH_NC(N, C) \
+    do {                   \
+        if (big) RT_LAUNCH(N, C, true); else RT_LAUNCH(N, C, false); \
+    } while (0)
     if (stack_needed <= 32) {
-        if (count) RT_LAUNCH(32, true); else RT_LAUNCH(32, false);
+        if (count) RT_LAUNCH_NC(32, true); else RT_LAUNCH_NC(32, false);
     } else if (stack_needed <= 64) {
-        if (count) RT_LAUNCH(64, true); else RT_LAUNCH(64, false);
+        if (count) RT_LAUNCH_NC(64, true); else RT_LAUNCH_NC(64, false);
     } else {
         return hipErrorInvalidValue;
     }
+#undef RT_LAUNCH_NC
 #undef RT_LAUNCH
     hipError_t e2 = hipGetLastError();
     if (e2 != hipSuccess) return e2;
@@ -782,16 +798,18 @@ uint32_t persistent_tile_count(const DevCam& cam, const DevRows& rows) {
     return ((cam.W + kPT - 1u) / kPT) * ((rows.local_rows + kPT - 1u) / kPT);
 }
 
-int persistent_blocks_per_cu(uint32_t stack_needed, bool count) {
+int persistent_blocks_per_cu(uint32_t stack_needed, bool count, bool big) {
     int n = 0;
     hipError_t e;
+#define RT_OCC(N, C, B) hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, path_kernel_persistent<N, C, B>, kBlock, 0)
     if (stack_needed <= 32) {
-        e = count ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, path_kernel_persistent<32, true>, kBlock, 0)
-                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, path_kernel_persistent<32, false>, kBlock, 0);
+        e = count ? (big ? RT_OCC(32, true, true) : RT_OCC(32, true, false))
+                  : (big ? RT_OCC(32, false, true) : RT_OCC(32, false, false));
     } else {
-        e = count ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, path_kernel_persistent<64, true>, kBlock, 0)
-                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, path_kernel_persistent<64, false>, kBlock, 0);
+        e = count ? (big ? RT_OCC(64, true, true) : RT_OCC(64, true, false))
+                  : (big ? RT_OCC(64, false, true) : RT_OCC(64, false, false));
     }
+#undef RT_OCC
     return e == hipSuccess && n > 0 ? n : 1;
 }
 

@@ -21,10 +21,10 @@ hipError_t launch_path_kernel(const DevScene& sc, const DevCam& cam, const DevRo
 // order from an earlier launch.
 hipError_t launch_persistent_kernel(const DevScene& sc, const DevCam& cam, const DevRows& rows, const DevFrame& fr,
                                     DevQueue q, uint32_t* order_out, uint32_t n_frames, uint32_t stack_needed,
-                                    bool count, uint32_t n_blocks, hipStream_t stream);
+                                    bool count, bool big, uint32_t n_blocks, hipStream_t stream);
 uint32_t persistent_tile_count(const DevCam& cam, const DevRows& rows);
 
 // Workgroups of the persistent kernel one CU can hold (occupancy query).
-int persistent_blocks_per_cu(uint32_t stack_needed, bool count);
+int persistent_blocks_per_cu(uint32_t stack_needed, bool count, bool big);
 
 }  // namespace rt

@@ -193,10 +193,14 @@ int render(rt_ctx* c, const rt_cam_data& cam, uint32_t n_frames) {
     sc.node_off = (uint32_t)c->node_off;
     sc.tri_test_off = (uint32_t)c->tri_test_off;
     sc.inst_off = (uint32_t)c->inst_off;
+    sc.node_unit = (uint32_t)(c->node_off / 64);
+    sc.tri_test_unit = (uint32_t)(c->tri_test_off / 64);
     sc.n_instances = c->n_instances;
     sc.fast_div = c->fast_div ? 1u : 0u;
-    // the persistent kernel names items by 32-bit byte offsets into the arena
-    const bool offsets_fit = c->arena_bytes <= 0xFFFFFFFFull;
+    // the persistent kernel names items by 32-bit byte offsets into the arena, or by 32-bit record
+    // numbers (64-byte units) when the arena is 4 GiB or more; RT_BIG_OFFSETS forces the latter (tests)
+    const bool big = c->arena_bytes > 0xFFFFFFFFull || std::getenv("RT_BIG_OFFSETS") != nullptr;
+    const bool offsets_fit = c->arena_bytes / 64 <= 0xFFFFFFFEull;
     DevCam dc = make_cam(cam, c->frame_stride, c->seed_mode);
     DevRows rows;
     rows.strip_h = c->world > 1 ? c->strip_h : cam.canvas_height;
@@ -252,13 +256,13 @@ int render(rt_ctx* c, const rt_cam_data& cam, uint32_t n_frames) {
             order_out = c->d_tile_order[next];
             c->order_current = next;
         }
-        int per_cu = persistent_blocks_per_cu(stack_needed, count);
+        int per_cu = persistent_blocks_per_cu(stack_needed, count, big);
         if (const char* e = std::getenv("RT_BLOCKS_PER_CU")) {  // tuning knob: fewer resident workgroups
             int v = std::atoi(e);
             if (v >= 1 && v < per_cu) per_cu = v;
         }
         const uint32_t n_blocks = (uint32_t)(c->n_cus * per_cu);
-        RT_HIP(c, launch_persistent_kernel(sc, dc, rows, fr, q, order_out, n_frames, stack_needed, count, n_blocks,
+        RT_HIP(c, launch_persistent_kernel(sc, dc, rows, fr, q, order_out, n_frames, stack_needed, count, big, n_blocks,
                                            c->stream));
     }
     RT_HIP(c, hipEventRecord(c->ev1, c->stream));

@@ -498,3 +498,14 @@ def test_moving_instances_between_frames_equals_uploading_the_moved_scene():
         bad["object_id"][0] = 99
         with pytest.raises(RtError):
             app.update_instances(bad)
+
+
+def test_record_number_item_names_for_arenas_beyond_4_gib(monkeypatch):
+    """Above 4 GiB of nodes and triangle records the persistent kernel names its items by record
+    number instead of byte offset.  RT_BIG_OFFSETS forces that variant on scenes the oracle can
+    render."""
+    monkeypatch.setenv("RT_BIG_OFFSETS", "1")
+    scene, cam = terrain_scene(200, 112, n=60, depth=8, threads=4, leaf_max=4)
+    check_against_oracle(scene, cam, frames=2)
+    scene, cam = default_scene(128, 72)
+    check_against_oracle(scene, cam, frames=3)
