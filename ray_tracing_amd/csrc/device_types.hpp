@@ -147,6 +147,7 @@ struct DevQueue {
     // not end on a few lanes finishing them alone.
     const uint32_t* order;
     uint32_t* cost;
+    uint32_t deal;  // how order_tiles_kernel shares the sorted tiles out: 1 dealt in turn, 0 a band per queue
 };
 
 struct DevFrame {

@@ -704,12 +704,20 @@ __global__ __launch_bounds__(kBlock) void present_kernel(DevCam cam, DevRows row
     reinterpret_cast<float4*>(fr.present)[idx] = gamma_correct(present_from_acc(fwm_last, acc));
 }
 
-// Next launch's tile order from this launch's costs: one workgroup per queue range, a counting
-// sort into 32 cost classes, dearest class first.  Within a class the order is whatever the
-// atomics make it: the order of pixels changes no pixel's value.
+// Next launch's tile order from this launch's costs: a counting sort into 32 cost classes,
+// dearest class first.  Within a class the order is whatever the atomics make it: the order of
+// pixels changes no pixel's value.  Two ways of sharing the tiles out over the 8 queues:
+//   banded (8 workgroups, one per queue): every queue keeps its contiguous band of the canvas --
+//     an XCD's L2 keeps seeing neighbouring rays -- and sorts the tiles inside it;
+//   dealt (1 workgroup): all tiles are sorted together and dealt to the queues in turn, so every
+//     queue runs from the dearest tiles of the canvas to the cheapest and the launch ends on
+//     short pixels everywhere.  That shortens the tail, which is what a launch of one or two
+//     frames mostly consists of; over many frames the bands' locality is worth more.
 __global__ __launch_bounds__(kBlock) void order_tiles_kernel(DevQueue q, uint32_t* order_out) {
     __shared__ uint32_t s_count[32], s_start[32];
-    const uint32_t t0 = q.first_item[blockIdx.x] >> kPTShift, t1 = q.first_item[blockIdx.x + 1] >> kPTShift;
+    const bool dealt = q.deal != 0u;
+    const uint32_t t0 = dealt ? 0u : q.first_item[blockIdx.x] >> kPTShift;
+    const uint32_t t1 = (dealt ? q.first_item[8] : q.first_item[blockIdx.x + 1]) >> kPTShift;
     if (threadIdx.x < 32) s_count[threadIdx.x] = 0;
     __syncthreads();
     // a full tile's cost is 64 pixels x 1..10+ segments; 24 per class keeps the classes fine enough
@@ -724,7 +732,10 @@ __global__ __launch_bounds__(kBlock) void order_tiles_kernel(DevQueue q, uint32_
         }
     }
     __syncthreads();
-    for (uint32_t t = t0 + threadIdx.x; t < t1; t += kBlock) order_out[t0 + atomicAdd(&s_start[cls(q.cost[t])], 1u)] = t;
+    for (uint32_t t = t0 + threadIdx.x; t < t1; t += kBlock) {
+        const uint32_t r = atomicAdd(&s_start[cls(q.cost[t])], 1u);  // rank in the sorted order
+        order_out[dealt ? (q.first_item[r & 7u] >> kPTShift) + (r >> 3) : t0 + r] = t;
+    }
 }
 
 hipError_t launch_path_kernel(const DevScene& sc, const DevCam& cam, const DevRows& rows, const DevFrame& fr,
@@ -755,7 +766,9 @@ hipError_t launch_persistent_kernel(const DevScene& sc, const DevCam& cam, const
     const uint32_t tiles_y = (rows.local_rows + kPT - 1u) / kPT;
     const uint32_t n_tiles = q.tiles_x * tiles_y;
     if (n_tiles == 0 || n_blocks == 0) return hipSuccess;
-    for (uint32_t i = 0; i <= 8; ++i) q.first_item[i] = (uint32_t)(((uint64_t)n_tiles * i) / 8u) * (kPT * kPT);
+    // queue i holds the tiles of rank i, i + 8, i + 16, ... of whatever order is in force
+    q.first_item[0] = 0;
+    for (uint32_t i = 0; i < 8; ++i) q.first_item[i + 1] = q.first_item[i] + ((n_tiles - i + 7u) / 8u) * (kPT * kPT);
     hipError_t e = hipMemsetAsync(q.head, 0, 8 * 32 * sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
     if (q.cost && (e = hipMemsetAsync(q.cost, 0, (size_t)n_tiles * sizeof(uint32_t), stream)) != hipSuccess) return e;
@@ -778,7 +791,7 @@ hipError_t launch_persistent_kernel(const DevScene& sc, const DevCam& cam, const
     hipError_t e2 = hipGetLastError();
     if (e2 != hipSuccess) return e2;
     if (q.cost && order_out) {
-        hipLaunchKernelGGL(order_tiles_kernel, dim3(8), block, 0, stream, q, order_out);
+        hipLaunchKernelGGL(order_tiles_kernel, dim3(q.deal ? 1 : 8), block, 0, stream, q, order_out);
         if ((e2 = hipGetLastError()) != hipSuccess) return e2;
     }
     if (!fr.present) return hipSuccess;

@@ -231,6 +231,9 @@ int render(rt_ctx* c, const rt_cam_data& cam, uint32_t n_frames) {
         q.w_ctl = c->vote_w[0];
         q.w_box = c->vote_w[1];
         q.w_leaf = c->vote_w[2];
+        // the order this launch leaves behind is for the next launch, most likely one of the same length
+        q.deal = n_frames <= 4u ? 1u : 0u;
+        if (const char* e = std::getenv("RT_TILE_DEAL")) q.deal = std::atoi(e) != 0 ? 1u : 0u;  // tuning knob
         uint32_t* order_out = nullptr;
         if (c->tile_order_enabled) {
             const uint32_t n_tiles = persistent_tile_count(dc, rows);

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Time of one lone 1080p frame of the bench scene (rt_render_frames(1) from a zeroed
-accumulator), best of 5, under whatever RT_* tuning variables are set."""
+"""Time of launches of 1, 2, 4 and 16 fused 1080p frames of the bench scene (from a zeroed
+accumulator, six launches each: the first one still runs in the plain tile order), under whatever
+RT_* tuning variables are set."""
 import os
 import sys
 
@@ -11,13 +12,14 @@ from ray_tracing_amd import _lib as L  # noqa: E402
 
 scene, cam0, _ = bench.build_scene("c3", 4, 16, 700)
 app = App.create(L.CamData.from_buffer_copy(cam0), scene)
-times = []
-for _ in range(6):
-    app.cam_data = L.CamData.from_buffer_copy(cam0)
-    app.clear_acc()
-    app.render_frames(1)
-    app.synchronize()
-    times.append(app.last_render_ms())
-print(" ".join(f"{k}={v}" for k, v in os.environ.items() if k.startswith("RT_")), "lone frame ms:",
-      " ".join(f"{t:.2f}" for t in times), flush=True)
+for n in (1, 2, 4, 8, 16):
+    times = []
+    for _ in range(6):
+        app.cam_data = L.CamData.from_buffer_copy(cam0)
+        app.clear_acc()
+        app.render_frames(n)
+        app.synchronize()
+        times.append(app.last_render_ms())
+    print(" ".join(f"{k}={v}" for k, v in os.environ.items() if k.startswith("RT_")), f"{n} frame(s), ms:",
+          " ".join(f"{t:.2f}" for t in times), flush=True)
 app.destroy()
