@@ -71,7 +71,26 @@ enum {
      * 1 = it hashes zeros instead: get_seed(frame, x, y, 0, 0, 0).  Samples become
      *     independent of each other, which sample-splitting across GPUs needs.
      *     Not the reference's sequence: comparable to it only statistically. */
-    RT_OPT_SEED_MODE = 6
+    RT_OPT_SEED_MODE = 6,
+    /* Tuning and test switches of the persistent kernel.  None of them changes a pixel.
+     * 1 (default) = hand the 8x8 tiles out in the cost order learnt from the previous launch of
+     *     the same canvas; 0 = always in plain order. */
+    RT_OPT_TILE_ORDER = 7,
+    /* Weights of the wave's vote between control, box and triangle steps: three bytes,
+     * control | box << 8 | triangle << 16, each 1..255.  Default 3, 2, 6. */
+    RT_OPT_VOTE_WEIGHTS = 8,
+    /* Resident workgroups per CU: 0 (default) = as many as fit, else at most this many. */
+    RT_OPT_BLOCKS_PER_CU = 9,
+    /* 1 = name BVH items by 64-byte record number even when byte offsets would fit (the
+     *     addressing scenes of 4 GiB and more get by themselves).  default 0 */
+    RT_OPT_FORCE_BIG_OFFSETS = 10,
+    /* 0 = form every slab-test quotient by IEEE division instead of multiplying by a cached
+     *     correctly rounded reciprocal.  default 1 */
+    RT_OPT_FAST_DIV = 11,
+    /* How the cost-sorted tiles are shared out over the 8 queues: 1 = dealt in turn, 0 = a
+     * contiguous band of the canvas per queue, -1 (default) = dealt for launches of up to four
+     * frames, banded for longer ones. */
+    RT_OPT_TILE_DEAL = 12
 };
 
 /* ---- lifecycle: vulkan::App::create / App::destroy (vulkan.rs:124-168, 374) ---- */

@@ -54,6 +54,11 @@ struct rt_ctx {
     bool tile_order_enabled = true;
     int n_cus = 0;
     int vote_w[3] = {3, 2, 6};  // vote weights: control, box, triangle steps
+    int tile_deal = -1;          // -1: by launch length; 0 / 1: RT_OPT_TILE_DEAL
+    int blocks_per_cu = 0;       // 0: as many as fit; RT_OPT_BLOCKS_PER_CU
+    bool force_big_offsets = false;
+    bool fast_div_enabled = true;
+    int per_cu_cache[2][2][2] = {{{0, 0}, {0, 0}}, {{0, 0}, {0, 0}}};  // occupancy answers, 0 = not asked yet
 
     // options
     int pipeline = 1;
@@ -177,11 +182,59 @@ DevCam make_cam(const rt_cam_data& cam, uint32_t frame_stride, uint32_t seed_mod
     return d;
 }
 
-int render(rt_ctx* c, const rt_cam_data& cam, uint32_t n_frames) {
+// Where the persistent kernel's queue heads, tile costs and tile orders live, and the host-side
+// state of the cost-aware order that goes with those buffers.
+struct QueueBufs {
+    uint32_t* head = nullptr;
+    uint32_t* cost = nullptr;
+    uint32_t* order[2] = {nullptr, nullptr};
+    int* order_current = nullptr;
+    uint32_t* order_sig = nullptr;
+};
+
+int blocks_per_cu(rt_ctx* c, uint32_t stack_needed, bool count, bool big) {
+    int& cached = c->per_cu_cache[stack_needed > 32 ? 1 : 0][count ? 1 : 0][big ? 1 : 0];
+    if (cached == 0) cached = persistent_blocks_per_cu(stack_needed, count, big);
+    int per_cu = cached;
+    if (c->blocks_per_cu >= 1 && c->blocks_per_cu < per_cu) per_cu = c->blocks_per_cu;
+    return per_cu;
+}
+
+// The context's own buffers, grown to `n_tiles` when needed.
+int ctx_queue_bufs(rt_ctx* c, uint32_t n_tiles, QueueBufs& qb) {
+    qb.head = c->d_queue;
+    if (!c->tile_order_enabled) return RT_OK;
+    if (n_tiles > c->tile_capacity) {
+        free_dev(c->d_tile_cost);
+        free_dev(c->d_tile_order[0]);
+        free_dev(c->d_tile_order[1]);
+        c->tile_capacity = 0;
+        c->order_current = -1;
+        RT_HIP(c, hipMalloc(&c->d_tile_cost, (size_t)n_tiles * 4));
+        RT_HIP(c, hipMalloc(&c->d_tile_order[0], (size_t)n_tiles * 4));
+        RT_HIP(c, hipMalloc(&c->d_tile_order[1], (size_t)n_tiles * 4));
+        c->tile_capacity = n_tiles;
+    }
+    qb.cost = c->d_tile_cost;
+    qb.order[0] = c->d_tile_order[0];
+    qb.order[1] = c->d_tile_order[1];
+    qb.order_current = &c->order_current;
+    qb.order_sig = c->order_sig;
+    return RT_OK;
+}
+
+// One launch of `n_frames` frames into the buffers of `fr`.  `own_buffers`: the frame and queue
+// buffers are the context's and may be (re)allocated here; otherwise `fr` and `qb` come from the
+// caller and nothing is allocated.
+int render(rt_ctx* c, const rt_cam_data& cam, uint32_t n_frames, const DevFrame* caller_frame,
+           const QueueBufs* caller_bufs) {
     if (!c->have_scene) return fail(c, RT_ERR_NO_SCENE, "rt_upload_scene has not been called");
     if (cam.debug_information > RT_DEBUG_BVH_INTERSECTION) return fail(c, RT_ERR_INVALID, "bad debug_information");
-    int rc = ensure_frame(c, cam.canvas_width, cam.canvas_height);
-    if (rc != RT_OK) return rc;
+    const bool own_buffers = caller_frame == nullptr;
+    if (own_buffers) {
+        int rc = ensure_frame(c, cam.canvas_width, cam.canvas_height);
+        if (rc != RT_OK) return rc;
+    }
     if (n_frames == 0) return RT_OK;
 
     DevScene sc;
@@ -196,10 +249,10 @@ int render(rt_ctx* c, const rt_cam_data& cam, uint32_t n_frames) {
     sc.node_unit = (uint32_t)(c->node_off / 64);
     sc.tri_test_unit = (uint32_t)(c->tri_test_off / 64);
     sc.n_instances = c->n_instances;
-    sc.fast_div = c->fast_div ? 1u : 0u;
+    sc.fast_div = (c->fast_div && c->fast_div_enabled) ? 1u : 0u;
     // the persistent kernel names items by 32-bit byte offsets into the arena, or by 32-bit record
-    // numbers (64-byte units) when the arena is 4 GiB or more; RT_BIG_OFFSETS forces the latter (tests)
-    const bool big = c->arena_bytes > 0xFFFFFFFFull || std::getenv("RT_BIG_OFFSETS") != nullptr;
+    // numbers (64-byte units) when the arena is 4 GiB or more (RT_OPT_FORCE_BIG_OFFSETS: always)
+    const bool big = c->arena_bytes > 0xFFFFFFFFull || c->force_big_offsets;
     const bool offsets_fit = c->arena_bytes / 64 <= 0xFFFFFFFEull;
     DevCam dc = make_cam(cam, c->frame_stride, c->seed_mode);
     DevRows rows;
@@ -208,65 +261,65 @@ int render(rt_ctx* c, const rt_cam_data& cam, uint32_t n_frames) {
     rows.world = c->world;
     rows.local_rows = local_rows(cam.canvas_height, rows.strip_h, c->rank, c->world);
     DevFrame fr;
-    fr.acc = c->d_acc;
-    fr.present = c->present ? c->d_present : nullptr;
-    fr.hit_triangle = c->probe_hits ? c->d_hit_tri : nullptr;
-    fr.hit_instance = c->probe_hits ? c->d_hit_inst : nullptr;
-    fr.hit_t_bits = c->probe_hits ? c->d_hit_t : nullptr;
-    fr.box_tests = c->counters ? c->d_box : nullptr;
-    fr.triangle_tests = c->counters ? c->d_tritests : nullptr;
+    if (own_buffers) {
+        fr.acc = c->d_acc;
+        fr.present = c->present ? c->d_present : nullptr;
+        fr.hit_triangle = c->probe_hits ? c->d_hit_tri : nullptr;
+        fr.hit_instance = c->probe_hits ? c->d_hit_inst : nullptr;
+        fr.hit_t_bits = c->probe_hits ? c->d_hit_t : nullptr;
+        fr.box_tests = c->counters ? c->d_box : nullptr;
+        fr.triangle_tests = c->counters ? c->d_tritests : nullptr;
+    } else {
+        fr = *caller_frame;
+    }
     fr.stats = c->d_stats;
 
     // the debug heat-maps read the counters (trace.rs:97-125)
-    const bool count = c->counters || cam.debug_information != RT_DEBUG_NONE;
+    const bool count = (own_buffers && c->counters) || cam.debug_information != RT_DEBUG_NONE;
     const uint32_t stack_needed = c->max_depth > 1 ? c->max_depth - 1 : 1;
 
+    if (!own_buffers && (c->pipeline == 0 || !offsets_fit))
+        return fail(c, RT_ERR_INVALID, "the no-allocation entry point runs the persistent kernel only");
     RT_HIP(c, hipEventRecord(c->ev0, c->stream));
     if (c->pipeline == 0 || !offsets_fit) {
         RT_HIP(c, launch_path_kernel(sc, dc, rows, fr, n_frames, stack_needed, count, c->stream));
     } else {
+        const uint32_t n_tiles = persistent_tile_count(dc, rows);
+        QueueBufs qb;
+        if (own_buffers) {
+            int rc = ctx_queue_bufs(c, n_tiles, qb);
+            if (rc != RT_OK) return rc;
+        } else {
+            qb = *caller_bufs;
+            if (!c->tile_order_enabled) qb.cost = nullptr;
+        }
         DevQueue q;
         std::memset(&q, 0, sizeof q);
-        q.head = c->d_queue;
+        q.head = qb.head;
         q.w_ctl = c->vote_w[0];
         q.w_box = c->vote_w[1];
         q.w_leaf = c->vote_w[2];
         // the order this launch leaves behind is for the next launch, most likely one of the same length
-        q.deal = n_frames <= 4u ? 1u : 0u;
-        if (const char* e = std::getenv("RT_TILE_DEAL")) q.deal = std::atoi(e) != 0 ? 1u : 0u;  // tuning knob
+        q.deal = c->tile_deal >= 0 ? (uint32_t)c->tile_deal : (n_frames <= 4u ? 1u : 0u);
         uint32_t* order_out = nullptr;
-        if (c->tile_order_enabled) {
-            const uint32_t n_tiles = persistent_tile_count(dc, rows);
+        int next = -1;
+        if (qb.cost) {
             const uint32_t sig[5] = {dc.W, dc.H, rows.strip_h, rows.rank, rows.world};
-            if (n_tiles > c->tile_capacity) {
-                free_dev(c->d_tile_cost);
-                free_dev(c->d_tile_order[0]);
-                free_dev(c->d_tile_order[1]);
-                c->tile_capacity = 0;
-                RT_HIP(c, hipMalloc(&c->d_tile_cost, (size_t)n_tiles * 4));
-                RT_HIP(c, hipMalloc(&c->d_tile_order[0], (size_t)n_tiles * 4));
-                RT_HIP(c, hipMalloc(&c->d_tile_order[1], (size_t)n_tiles * 4));
-                c->tile_capacity = n_tiles;
-                c->order_current = -1;
+            if (std::memcmp(sig, qb.order_sig, sizeof sig) != 0) {
+                *qb.order_current = -1;  // another canvas or another share of it: start from the plain order
+                std::memcpy(qb.order_sig, sig, sizeof sig);
             }
-            if (std::memcmp(sig, c->order_sig, sizeof sig) != 0) {
-                c->order_current = -1;  // another canvas or another share of it: start from the plain order
-                std::memcpy(c->order_sig, sig, sizeof sig);
-            }
-            q.cost = c->d_tile_cost;
-            q.order = c->order_current >= 0 ? c->d_tile_order[c->order_current] : nullptr;
-            const int next = c->order_current == 0 ? 1 : 0;
-            order_out = c->d_tile_order[next];
-            c->order_current = next;
+            q.cost = qb.cost;
+            q.order = *qb.order_current >= 0 ? qb.order[*qb.order_current] : nullptr;
+            next = *qb.order_current == 0 ? 1 : 0;
+            order_out = qb.order[next];
+            // the buffer written below only counts as an order once every launch has been enqueued
+            *qb.order_current = -1;
         }
-        int per_cu = persistent_blocks_per_cu(stack_needed, count, big);
-        if (const char* e = std::getenv("RT_BLOCKS_PER_CU")) {  // tuning knob: fewer resident workgroups
-            int v = std::atoi(e);
-            if (v >= 1 && v < per_cu) per_cu = v;
-        }
-        const uint32_t n_blocks = (uint32_t)(c->n_cus * per_cu);
+        const uint32_t n_blocks = (uint32_t)(c->n_cus * blocks_per_cu(c, stack_needed, count, big));
         RT_HIP(c, launch_persistent_kernel(sc, dc, rows, fr, q, order_out, n_frames, stack_needed, count, big, n_blocks,
                                            c->stream));
+        if (qb.cost && n_tiles != 0) *qb.order_current = next;
     }
     RT_HIP(c, hipEventRecord(c->ev1, c->stream));
     c->timed = true;
@@ -303,15 +356,6 @@ int rt_create(int device, rt_ctx** out) {
     hipDeviceProp_t prop;
     if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return bail("hipGetDeviceProperties", e);
     c->n_cus = prop.multiProcessorCount;
-    if (std::getenv("RT_NO_TILE_ORDER")) c->tile_order_enabled = false;  // tuning knob
-    if (const char* w = std::getenv("RT_VOTE_WEIGHTS")) {
-        int a = 1, b = 1, d = 1;
-        if (std::sscanf(w, "%d,%d,%d", &a, &b, &d) == 3 && a > 0 && b > 0 && d > 0) {
-            c->vote_w[0] = a;
-            c->vote_w[1] = b;
-            c->vote_w[2] = d;
-        }
-    }
     *out = c;
     return RT_OK;
 }
@@ -336,6 +380,9 @@ const char* rt_last_error(const rt_ctx* c) { return c ? c->err.c_str() : g_creat
 
 int rt_set_stream(rt_ctx* c, void* hip_stream) {
     if (!c) return RT_ERR_INVALID;
+    // launches on the old stream still use the queue, cost and order buffers the next launch reuses
+    RT_HIP(c, hipSetDevice(c->device));
+    RT_HIP(c, hipStreamSynchronize(c->stream));
     c->stream = static_cast<hipStream_t>(hip_stream);
     return RT_OK;
 }
@@ -357,6 +404,29 @@ int rt_set_option(rt_ctx* c, int option, int64_t value) {
         case RT_OPT_SEED_MODE:
             if (value < 0 || value > 1) return fail(c, RT_ERR_INVALID, "unknown seed mode");
             c->seed_mode = (uint32_t)value;
+            return RT_OK;
+        case RT_OPT_TILE_ORDER:
+            c->tile_order_enabled = value != 0;
+            c->order_current = -1;
+            return RT_OK;
+        case RT_OPT_VOTE_WEIGHTS: {
+            const int a = (int)(value & 0xFF), b = (int)((value >> 8) & 0xFF), d = (int)((value >> 16) & 0xFF);
+            if (value < 0 || value > 0xFFFFFF || a == 0 || b == 0 || d == 0)
+                return fail(c, RT_ERR_INVALID, "vote weights: three bytes, each 1..255");
+            c->vote_w[0] = a;
+            c->vote_w[1] = b;
+            c->vote_w[2] = d;
+            return RT_OK;
+        }
+        case RT_OPT_BLOCKS_PER_CU:
+            if (value < 0 || value > 8) return fail(c, RT_ERR_INVALID, "blocks per CU: 0 (as many as fit) .. 8");
+            c->blocks_per_cu = (int)value;
+            return RT_OK;
+        case RT_OPT_FORCE_BIG_OFFSETS: c->force_big_offsets = value != 0; return RT_OK;
+        case RT_OPT_FAST_DIV: c->fast_div_enabled = value != 0; return RT_OK;
+        case RT_OPT_TILE_DEAL:
+            if (value < -1 || value > 1) return fail(c, RT_ERR_INVALID, "tile deal: -1 (by launch length), 0 or 1");
+            c->tile_deal = (int)value;
             return RT_OK;
         default: return fail(c, RT_ERR_INVALID, "unknown option");
     }
@@ -400,8 +470,12 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_info* info, const rt_vertex* verti
     c->h_objects = g.objects;
     c->n_instances = (uint32_t)g.instances.size();
     c->max_depth = g.max_depth;
-    c->fast_div = g.fast_div && std::getenv("RT_NO_FAST_DIV") == nullptr;
+    c->fast_div = g.fast_div;
     c->have_scene = true;
+    // ask for the occupancy of the kernel variants this scene can launch now, so that a later
+    // render call has nothing left to look up
+    const uint32_t stack_needed = c->max_depth > 1 ? c->max_depth - 1 : 1;
+    for (int big = 0; big < 2; ++big) (void)blocks_per_cu(c, stack_needed, false, big != 0);
     return RT_OK;
 }
 
@@ -461,13 +535,13 @@ int rt_set_rows(rt_ctx* c, uint32_t strip_height, uint32_t rank, uint32_t world)
 int rt_render_frame(rt_ctx* c, const rt_cam_data* cam) {
     if (!c || !cam) return RT_ERR_INVALID;
     RT_HIP(c, hipSetDevice(c->device));
-    return render(c, *cam, 1);
+    return render(c, *cam, 1, nullptr, nullptr);
 }
 
 int rt_render_frames(rt_ctx* c, rt_cam_data* cam, uint32_t n) {
     if (!c || !cam) return RT_ERR_INVALID;
     RT_HIP(c, hipSetDevice(c->device));
-    int rc = render(c, *cam, n);
+    int rc = render(c, *cam, n, nullptr, nullptr);
     if (rc != RT_OK) return rc;
     for (uint32_t i = 0; i < n; ++i) {  // main.rs:147-148
         cam->frame += c->frame_stride;

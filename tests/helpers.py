@@ -14,12 +14,14 @@ def copy_cam(cam):
     return L.CamData.from_buffer_copy(cam)
 
 
-def gpu_render(scene, cam, frames, counters=True, materials=None, pipeline=1):
+def gpu_render(scene, cam, frames, counters=True, materials=None, pipeline=1, options=()):
     app = App.create(copy_cam(cam), scene, device=0)
     try:
         app.set_option(RT_OPT_PROBE_HITS, 1)
         app.set_option(RT_OPT_COUNTERS, int(counters))
         app.set_option(RT_OPT_PIPELINE, pipeline)
+        for opt, value in options:
+            app.set_option(opt, value)
         if materials is not None:
             app.set_materials(materials)
         app.render_frames(frames)

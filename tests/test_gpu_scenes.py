@@ -25,8 +25,8 @@ pytestmark = pytest.mark.gpu
 F = np.float32
 
 
-def check_against_oracle(scene, cam, frames=2, materials=None, pipeline=1, nan_equal=False):
-    g = gpu_render(scene, cam, frames, materials=materials, pipeline=pipeline)
+def check_against_oracle(scene, cam, frames=2, materials=None, pipeline=1, nan_equal=False, options=()):
+    g = gpu_render(scene, cam, frames, materials=materials, pipeline=pipeline, options=options)
     ref = O.OracleRenderer(scene, cam, trig=O.TRIG_DET, materials=materials).render(frames)
     tri, inst, tb = g["hits"]
     assert_bits_equal(tri, ref.hit_triangle, "triangle_id")
@@ -500,12 +500,26 @@ def test_moving_instances_between_frames_equals_uploading_the_moved_scene():
             app.update_instances(bad)
 
 
-def test_record_number_item_names_for_arenas_beyond_4_gib(monkeypatch):
+def test_record_number_item_names_for_arenas_beyond_4_gib():
     """Above 4 GiB of nodes and triangle records the persistent kernel names its items by record
-    number instead of byte offset.  RT_BIG_OFFSETS forces that variant on scenes the oracle can
-    render."""
-    monkeypatch.setenv("RT_BIG_OFFSETS", "1")
+    number instead of byte offset.  RT_OPT_FORCE_BIG_OFFSETS forces that variant on scenes the
+    oracle can render."""
+    big = [(L.RT_OPT_FORCE_BIG_OFFSETS, 1)]
     scene, cam = terrain_scene(200, 112, n=60, depth=8, threads=4, leaf_max=4)
-    check_against_oracle(scene, cam, frames=2)
+    check_against_oracle(scene, cam, frames=2, options=big)
     scene, cam = default_scene(128, 72)
-    check_against_oracle(scene, cam, frames=3)
+    check_against_oracle(scene, cam, frames=3, options=big)
+
+
+def test_tuning_options_change_no_pixel():
+    """The persistent kernel's tuning switches (tile order, vote weights, resident workgroups,
+    plain division in the slab test, how sorted tiles are dealt) only move work around."""
+    scene, cam = terrain_scene(200, 112, n=60, depth=8, threads=4, leaf_max=4)
+    for opts in ([(L.RT_OPT_TILE_ORDER, 0)], [(L.RT_OPT_VOTE_WEIGHTS, 1 | 1 << 8 | 1 << 16)],
+                 [(L.RT_OPT_BLOCKS_PER_CU, 1)], [(L.RT_OPT_FAST_DIV, 0)], [(L.RT_OPT_TILE_DEAL, 0)],
+                 [(L.RT_OPT_TILE_DEAL, 1)]):
+        check_against_oracle(scene, cam, frames=2, options=opts)
+    with App.create(copy_cam(cam), scene) as app:
+        for opt, bad in ((L.RT_OPT_VOTE_WEIGHTS, 0), (L.RT_OPT_BLOCKS_PER_CU, 9), (L.RT_OPT_TILE_DEAL, 2)):
+            with pytest.raises(RtError):
+                app.set_option(opt, bad)
