@@ -134,6 +134,20 @@ int rt_render_frame(rt_ctx* ctx, const rt_cam_data* cam);
 /* n consecutive frames; after each one frame += 1 and frames_without_move += 1.0
  * exactly as the event loop does (main.rs:147-148).  *cam is updated. */
 int rt_render_frames(rt_ctx* ctx, rt_cam_data* cam, uint32_t n);
+/* No counterpart in the reference.  rt_render_frames for callers that cannot allocate device
+ * memory while they render (code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc): this call allocates and frees nothing, on the device or through any
+ * library.  The caller passes the frame buffers, both device memory of canvas_width *
+ * canvas_height RGBA floats on the context's GPU: `acc_device` is binding 7 (read and written:
+ * zero it before the first frame, lib.rs:57-60) and `present_device` binding 8 (written; NULL
+ * skips the gamma pass).  The kernel's own work memory (queue heads, per-tile costs, tile
+ * orders) is a fixed 3 MiB device array inside the library, one copy per GPU, shared by every
+ * context on that GPU: calls that overlap in time on one GPU race, so keep them on one stream or
+ * otherwise ordered.  Limits: the persistent kernel only (RT_OPT_PIPELINE 1, scenes below
+ * 256 GiB), no RT_OPT_PROBE_HITS / RT_OPT_COUNTERS (RT_ERR_INVALID), and a canvas of at most
+ * 262144 8x8-pixel tiles, about 16.7 M pixels (RT_ERR_LIMIT beyond).  Pixels are bit for bit
+ * those of rt_render_frames.  Needs rt_upload_scene first, like every render call. */
+int rt_render_frames_noalloc(rt_ctx* ctx, rt_cam_data* cam, uint32_t n, float* acc_device, float* present_device);
 int rt_synchronize(rt_ctx* ctx);
 
 /* ---- read-back.  n_pixels must be canvas_width*canvas_height of the last

@@ -112,6 +112,7 @@ SIGNATURES = {
     "rt_set_rows": (_i32, [_vp, _u32, _u32, _u32]),
     "rt_render_frame": (_i32, [_vp, _P(CamData)]),
     "rt_render_frames": (_i32, [_vp, _P(CamData), _u32]),
+    "rt_render_frames_noalloc": (_i32, [_vp, _P(CamData), _u32, _vp, _vp]),
     "rt_synchronize": (_i32, [_vp]),
     "rt_selftest_fastmath_device": (_i32, [C.c_int, _P(C.c_uint64)]),
     "rt_selftest_rcp_device": (_i32, [C.c_int, _P(C.c_uint32)]),

@@ -106,6 +106,12 @@ class App:
     def render_frames(self, n):
         self._check(self._lib.rt_render_frames(self._ctx, C.byref(self.cam_data), n))
 
+    def render_frames_noalloc(self, n, acc_ptr, present_ptr=None):
+        """rt_render_frames_noalloc: n frames into caller-owned device buffers (addresses as
+        integers), with no allocation inside the call."""
+        self._check(self._lib.rt_render_frames_noalloc(self._ctx, C.byref(self.cam_data), n, C.c_void_p(acc_ptr),
+                                                       C.c_void_p(present_ptr) if present_ptr else None))
+
     def synchronize(self):
         self._check(self._lib.rt_synchronize(self._ctx))
 

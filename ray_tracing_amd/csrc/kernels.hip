@@ -807,6 +807,57 @@ hipError_t launch_persistent_kernel(const DevScene& sc, const DevCam& cam, const
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------
+// Scratch of the render entry point that allocates nothing (rt_render_frames_noalloc): the
+// persistent kernel's queue heads, per-tile costs and the two tile-order buffers, in a
+// file-scope device array instead of hipMalloc'ed memory.  Every GPU the library runs on holds
+// its own copy at its own address until the process ends.  In host code the array's name is
+// only a handle for hipGetSymbolAddress: the address kernels and memsets are given is the one
+// that call returned for the current device.
+// ---------------------------------------------------------------------------
+namespace {
+
+struct NoAllocScratch {
+    uint32_t head[8 * 32];                     // queue heads, one 128-byte line each
+    uint32_t cost[kNoAllocMaxTiles];
+    uint32_t order[2][kNoAllocMaxTiles];
+};
+
+static __device__ __align__(256) unsigned char scratch[sizeof(NoAllocScratch)];
+
+constexpr int kMaxDevices = 64;
+struct ScratchHost {
+    NoAllocScratch* ptr = nullptr;  // device address of `scratch` on this GPU
+    int order_current = -1;         // tile-order state of the launches that share this GPU's scratch
+    uint32_t order_sig[5] = {0, 0, 0, 0, 0};
+};
+ScratchHost g_scratch[kMaxDevices];
+
+}  // namespace
+
+hipError_t noalloc_scratch_init(int device) {
+    if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+    if (g_scratch[device].ptr) return hipSuccess;
+    void* p = nullptr;
+    const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));  // `device` is current
+    if (e != hipSuccess) return e;
+    if (!p) return hipErrorInvalidSymbol;
+    g_scratch[device].ptr = static_cast<NoAllocScratch*>(p);
+    return hipSuccess;
+}
+
+bool noalloc_scratch_view(int device, NoAllocView* out) {
+    if (device < 0 || device >= kMaxDevices || !g_scratch[device].ptr) return false;
+    ScratchHost& h = g_scratch[device];
+    out->head = h.ptr->head;
+    out->cost = h.ptr->cost;
+    out->order[0] = h.ptr->order[0];
+    out->order[1] = h.ptr->order[1];
+    out->order_current = &h.order_current;
+    out->order_sig = h.order_sig;
+    return true;
+}
+
 uint32_t persistent_tile_count(const DevCam& cam, const DevRows& rows) {
     return ((cam.W + kPT - 1u) / kPT) * ((rows.local_rows + kPT - 1u) / kPT);
 }

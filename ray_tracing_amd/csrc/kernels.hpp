@@ -24,6 +24,22 @@ hipError_t launch_persistent_kernel(const DevScene& sc, const DevCam& cam, const
                                     bool count, bool big, uint32_t n_blocks, hipStream_t stream);
 uint32_t persistent_tile_count(const DevCam& cam, const DevRows& rows);
 
+// Scratch of the no-allocation render entry point: a device array of the code object, one copy
+// per GPU.  noalloc_scratch_init looks its address up once per device (call it with that device
+// current); noalloc_scratch_view hands out the pieces and the host-side tile-order state that
+// goes with them (shared by every context on that GPU).  Canvases of more than
+// kNoAllocMaxTiles 8x8-pixel tiles do not fit.
+constexpr uint32_t kNoAllocMaxTiles = 1u << 18;  // 16.7 M pixels, e.g. 5120 x 2880; 3 MiB of scratch per GPU
+struct NoAllocView {
+    uint32_t* head;
+    uint32_t* cost;
+    uint32_t* order[2];
+    int* order_current;
+    uint32_t* order_sig;  // 5 words
+};
+hipError_t noalloc_scratch_init(int device);
+bool noalloc_scratch_view(int device, NoAllocView* out);
+
 // Workgroups of the persistent kernel one CU can hold (occupancy query).
 int persistent_blocks_per_cu(uint32_t stack_needed, bool count, bool big);
 

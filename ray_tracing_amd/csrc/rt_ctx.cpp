@@ -356,6 +356,9 @@ int rt_create(int device, rt_ctx** out) {
     hipDeviceProp_t prop;
     if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return bail("hipGetDeviceProperties", e);
     c->n_cus = prop.multiProcessorCount;
+    // the address of this GPU's copy of the no-allocation entry point's scratch array; the lookup
+    // also loads the code object, so no later launch has to
+    if ((e = noalloc_scratch_init(device)) != hipSuccess) return bail("hipGetSymbolAddress(scratch)", e);
     *out = c;
     return RT_OK;
 }
@@ -542,6 +545,41 @@ int rt_render_frames(rt_ctx* c, rt_cam_data* cam, uint32_t n) {
     if (!c || !cam) return RT_ERR_INVALID;
     RT_HIP(c, hipSetDevice(c->device));
     int rc = render(c, *cam, n, nullptr, nullptr);
+    if (rc != RT_OK) return rc;
+    for (uint32_t i = 0; i < n; ++i) {  // main.rs:147-148
+        cam->frame += c->frame_stride;
+        cam->frames_without_move += 1.0f;
+    }
+    return RT_OK;
+}
+
+int rt_render_frames_noalloc(rt_ctx* c, rt_cam_data* cam, uint32_t n, float* acc_device, float* present_device) {
+    if (!c || !cam) return RT_ERR_INVALID;
+    if (!acc_device) return fail(c, RT_ERR_INVALID, "acc_device is NULL");
+    if (cam->canvas_width == 0 || cam->canvas_height == 0 ||
+        (uint64_t)cam->canvas_width * cam->canvas_height > 0x7FFFFFFFull)
+        return fail(c, RT_ERR_INVALID, "bad canvas size");
+    if (c->probe_hits || c->counters)
+        return fail(c, RT_ERR_INVALID, "RT_OPT_PROBE_HITS / RT_OPT_COUNTERS need buffers this entry point does not allocate");
+    const uint64_t tiles = (uint64_t)((cam->canvas_width + 7u) / 8u) * ((cam->canvas_height + 7u) / 8u);
+    if (tiles > kNoAllocMaxTiles)
+        return fail(c, RT_ERR_LIMIT, "canvas of " + std::to_string(tiles) + " 8x8 tiles exceeds the " +
+                                         std::to_string(kNoAllocMaxTiles) + " the static scratch holds");
+    RT_HIP(c, hipSetDevice(c->device));
+    NoAllocView v;
+    if (!noalloc_scratch_view(c->device, &v)) return fail(c, RT_ERR_HIP, "the scratch array of this device was never looked up");
+    QueueBufs qb;
+    qb.head = v.head;
+    qb.cost = v.cost;
+    qb.order[0] = v.order[0];
+    qb.order[1] = v.order[1];
+    qb.order_current = v.order_current;
+    qb.order_sig = v.order_sig;
+    DevFrame fr;
+    std::memset(&fr, 0, sizeof fr);
+    fr.acc = acc_device;
+    fr.present = present_device;
+    int rc = render(c, *cam, n, &fr, &qb);
     if (rc != RT_OK) return rc;
     for (uint32_t i = 0; i < n; ++i) {  // main.rs:147-148
         cam->frame += c->frame_stride;
