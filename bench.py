@@ -8,14 +8,15 @@ figures are quoted on ("c3"): a seeded ~1.0 M-triangle procedural scene at
 1920x1080, 16 accumulated one-sample frames per step, depth 10, scene resident
 in HBM before the timed region.  With N > 1 (launched by torch.distributed.run,
 one process per GPU) the canvas is dealt to the ranks in interleaved 8-row
-strips; there is no collective in the data path.  By default the canvas grows
-with N at a fixed aspect ratio (area x N: the same view, sampled more densely),
-so every GPU keeps one 1080p's worth of pixels: "weak" scaling.  `--scaling
-strong` keeps the 1920x1080 canvas for every N instead; that 25 ms job is
-bounded below by its longest pixel (16 dependent frames of up to 10 segments,
-about 10 ms of strictly serial steps), not by throughput.  A ray is one
-trace_ray invocation (shader/src/modules/trace.rs:195), primary and secondary
-alike; the count comes from the device's own counter.
+strips; there is no collective in the data path.  The job is the same for every
+N (1920x1080, 16 spp, the same scene): "strong" scaling.  That 19 ms job is
+bounded below by its longest pixel (16 dependent frames of up to 10 segments:
+`strong_scaling_floor` on the N = 1 line is the step time of a 1/64 share of the
+canvas, which no number of GPUs gets below).  For N > 1 the line also carries
+`weak_scaling`: the same view on a canvas of N times the area, so that every GPU
+keeps one 1080p's worth of pixels (`--scaling weak` makes that the headline).
+A ray is one trace_ray invocation (shader/src/modules/trace.rs:195), primary and
+secondary alike; the count comes from the device's own counter.
 
 The other configurations, for reference numbers (not the driver's bench
 line): c2 (10k tessellated spheres, 1 spp, 5 segments), c4 (10 M triangles, 4K,
@@ -25,6 +26,7 @@ accumulator per step), c5 (closed box, diffuse, 9 segments).
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import ctypes as C
 import json
 import math
 import os
@@ -127,8 +129,13 @@ def main():
     ap.add_argument("--leaf-max", type=int, default=4,
                     help="largest leaf the BVH builder leaves unsplit (the reference's builder: 16, bvh.rs:75)")
     ap.add_argument("--pipeline", type=int, default=1, help="kernel: 0 plain nested loops, 1 persistent state machine")
-    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
-                    help="N > 1, tile-partitioned configs: weak = canvas area x N (default), strong = fixed canvas")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="strong",
+                    help="N > 1, tile-partitioned configs: strong = the config's own canvas (default), "
+                         "weak = canvas area x N")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="only the headline measurement (for profiler runs: every launch of the kernel is then a step)")
+    ap.add_argument("--opt", action="append", default=[], metavar="ID=VALUE",
+                    help="rt_set_option(ID, VALUE) before rendering (tuning switches; none changes a pixel)")
     ap.add_argument("--present", type=int, default=1, help="0: skip the gamma-corrected present image (accumulator only)")
     args = ap.parse_args()
 
@@ -169,6 +176,9 @@ def main():
     app = App.create(L.CamData.from_buffer_copy(cam0), scene, device=device_index, stream=stream)
     app.set_option(RT_OPT_PIPELINE, args.pipeline)
     app.set_option(RT_OPT_PRESENT, args.present)
+    for kv in args.opt:
+        k, v = kv.split("=")
+        app.set_option(int(k), int(v))
     if partition == "tile":
         app.set_rows(STRIP_H, rank, world)
         first_frame, my_frames = 0, frames_per_step
@@ -215,49 +225,117 @@ def main():
     sched = app.sched_stats()
     app.set_option(RT_OPT_COUNTERS, 0)
 
+    def timed(n_steps, step):
+        """n_steps of `step` between two barriers; wall seconds (max over ranks), rays of all
+        ranks, and this rank's average HIP-event time per launch."""
+        sync()
+        app.reset_stats()
+        # HIP events on the stream the kernel is launched on (torch's current stream was handed
+        # to the library), one pair around every launch of the timed region
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_steps)]
+        t0 = time.perf_counter()
+        for k in range(n_steps):
+            step(ev[k])
+        sync()
+        dt = time.perf_counter() - t0
+        ms = sum(a.elapsed_time(b) for a, b in ev) / max(1, n_steps)
+        red_dev = "cpu" if rehearse else "cuda"
+        t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
+        r = torch.tensor([float(app.stats()["rays"])], dtype=torch.float64, device=red_dev)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dist.all_reduce(r, op=dist.ReduceOp.SUM)
+        return float(t.item()), float(r.item()), ms
+
+    # the first launch of a view: no tile order learnt yet (what follows every camera move)
+    first_launch = None
+    if world == 1 and partition == "tile" and not args.no_extras:
+        app.set_option(L.RT_OPT_TILE_ORDER, 1)  # forgets the order the counter pass left behind
+        dt, rays, ms = timed(1, one_step)
+        first_launch = {"kernel_ms": ms, "Mrays_per_s": rays / (ms * 1e-3) / 1e6,
+                        "what": "one step launched with no tile order learnt from an earlier launch of the view"}
+
     for _ in range(args.warmup):
         one_step()
-    sync()
-    app.reset_stats()
-    # HIP events on the stream the kernel is launched on (torch's current stream was handed
-    # to the library), one pair around every launch of the timed region
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        one_step(ev[k])
-    sync()
-    elapsed = time.perf_counter() - t0
-    kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / max(1, args.steps)  # average kernel time per launch
-    stats = app.stats()
-
-    red_dev = "cpu" if rehearse else "cuda"
-    t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
-    r = torch.tensor([float(stats["rays"])], dtype=torch.float64, device=red_dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dist.all_reduce(r, op=dist.ReduceOp.SUM)
-    elapsed = float(t.item())
-    total_rays = float(r[0].item())
+    elapsed, total_rays, kernel_ms = timed(args.steps, one_step)
     ms_per_step = elapsed / args.steps * 1e3
 
-    def measured_traffic():
-        """HBM-side bytes per launch from the committed rocprofv3 PMC passes of this very
-        workload (profiles/traffic_bench.json); None when no matching profile exists."""
+    extras = {}
+    if first_launch:
+        extras["first_launch_of_a_view"] = first_launch
+    if world == 1 and partition == "tile" and not args.no_extras:
+        # the reference's own mode: one render call per frame (main.rs:129-149)
+        def lone_frames(events=None):
+            app.cam_data = fresh_cam()
+            app.clear_acc()
+            if events:
+                events[0].record()
+            for _ in range(frames_per_step):
+                app.render_frames(1)
+            if events:
+                events[1].record()
+
+        for _ in range(2):
+            lone_frames()
+        dt, _, _ = timed(3, lone_frames)
+        extras["ms_per_lone_frame"] = dt / 3 / frames_per_step * 1e3
+        # what no number of GPUs gets below: the step time of a 1/64 share of the canvas (the
+        # longest pixel's chain of dependent frames and segments, plus a launch)
+        app.set_rows(STRIP_H, 0, 64)
+        for _ in range(2):
+            one_step()
+        dt, rays, ms = timed(5, one_step)
+        extras["strong_scaling_floor"] = {"share_of_canvas": 1.0 / 64, "ms_per_step": dt / 5 * 1e3, "kernel_ms": ms}
+        app.set_rows(STRIP_H, rank, world)
+    if world > 1 and partition == "tile" and scaling == "strong" and not args.no_extras:
+        # weak scaling beside the headline: the same view on N times the area
+        ww, wh = canvas_for(args.config, world, "weak")
+        cam_weak = L.CamData.from_buffer_copy(cam0)
+        cam_weak.canvas_width, cam_weak.canvas_height = ww, wh
+
+        def weak_step(events=None):
+            app.cam_data = L.CamData.from_buffer_copy(cam_weak)
+            app.clear_acc()
+            if events:
+                events[0].record()
+            launch()
+            if events:
+                events[1].record()
+
+        for _ in range(2):
+            weak_step()
+        dt, rays, ms = timed(max(2, args.steps // 2), weak_step)
+        extras["weak_scaling"] = {"canvas": [ww, wh], "Mrays_per_s": rays / dt / 1e6,
+                                  "ms_per_step": dt / max(2, args.steps // 2) * 1e3}
+
+    def committed_profile():
+        """Per-launch hardware counters of this very workload from the committed rocprofv3 PMC
+        passes (profiles/counters_bench.json); {} when no matching profile exists."""
         try:
-            with open(os.path.join(ROOT, "profiles", "traffic_bench.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "counters_bench.json")) as f:
                 tr = json.load(f)
             if tr["workload"] == workload and tr["n_gpus"] == world:
-                return tr["traffic_bytes_per_launch"], tr.get("valu_pipe_busy")
+                return tr
         except (OSError, KeyError, ValueError):
             pass
-        return None, None
+        return {}
 
     out = None
     if rank == 0:
-        # roofline of the one kernel of the step, on this rank's share of the work
+        # The one kernel of the step, on this rank's share of the work.  It is bound by vector
+        # instruction issue: `peak` is what the chip issues of full-rate vector instructions
+        # (v_mul_f32 / v_add_f32, 2 cycles per SIMD) at the kernel's own occupancy, measured now by
+        # the device micro-probe; `achieved` is the kernel's vector instructions per launch (hardware
+        # counter of the committed profile of this workload) over its HIP-event time.
+        prof = committed_profile()
+        probe = L.ValuProbe()
+        peak = None
+        if L.load().rt_probe_valu_issue(device_index, L.VALU_MIXES.index("mul_add"), 4, 2000, C.byref(probe)) == 0:
+            peak = probe.simds * probe.clock_mhz * 1e6 / probe.simd_cycles_per_inst / 1e9
+        insts = prof.get("valu_insts_per_launch")
+        achieved = insts / (kernel_ms * 1e-3) / 1e9 if insts else None
         rank_bytes = float(algorithmic_bytes(counted, n_inst))
-        achieved = rank_bytes / (kernel_ms * 1e-3) / 1e9
-        traffic, valu_busy = measured_traffic()
+        traffic = prof.get("traffic_bytes_per_launch")
         out = {
             "metric": "Mrays/s (primary+secondary)", "value": total_rays / elapsed / 1e6, "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -266,16 +344,24 @@ def main():
             "data": "synthetic",
             "config": {"workload": workload, "name": args.config, "partition": how,
                        "rays_per_step": total_rays / args.steps},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         # frac > 1: the reference's byte model counts every node and triangle a ray touches as
-                         # a memory read, the caches serve most of them (compare `traffic`); what the committed
-                         # profile shows to be the binding resource is VALU issue
-                         "valu_pipe_busy": valu_busy,
+            "roofline": {"bound": "valu_issue", "achieved": achieved, "peak": peak, "unit": "Ginst/s",
+                         "frac": achieved / peak if achieved and peak else None,
+                         "traffic": traffic,
                          "kernel": "path_kernel_persistent" if args.pipeline else "path_kernel",
-                         "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": rank_bytes,
+                         "kernel_ms": kernel_ms,
+                         "valu_insts_per_launch": insts,
+                         "probe": {"class": "v_mul_f32 / v_add_f32", "waves_per_simd": 4,
+                                   "simd_cycles_per_inst": probe.simd_cycles_per_inst, "clock_mhz": probe.clock_mhz},
+                         # the byte model of the reference's own data structures, and what reaches the
+                         # fabric: the working set is cache-resident, HBM is not the bound
+                         "hbm": {"algorithmic_bytes_per_launch": rank_bytes,
+                                 "algorithmic_GBps": rank_bytes / (kernel_ms * 1e-3) / 1e9,
+                                 "traffic_GBps": traffic / (kernel_ms * 1e-3) / 1e9 if traffic else None,
+                                 "peak_GBps": HBM_PEAK_GBS,
+                                 "traffic_frac_of_peak": traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if traffic else None},
                          "counters_per_launch": counted, "schedule_per_launch": sched},
         }
+        out.update(extras)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cam = L.CamData.from_buffer_copy(cam0)
         out["cpu_baseline"] = cpu_baseline(scene, cam, frames_cap=max(frames_per_step, 64))

@@ -287,6 +287,46 @@ int rt_selftest_rcp_device(int device, uint32_t* max_ulp_error);
  * any bit.  All three must be 0. */
 int rt_selftest_fastmath_device(int device, uint64_t mismatches[3]);
 
+/* Device micro-probe that prices the bound of the trace kernel, which is vector-instruction
+ * issue: how many cycles of one SIMD a wave64 vector instruction of a given class takes with
+ * `waves_per_simd` (1..8) waves resident on every SIMD of the chip.  Every wave runs an unrolled
+ * body of 64 independent instructions of the class for `duration_us` microseconds and counts
+ * the bodies.  simd_cycles_per_inst = window x clock x SIMDs / instructions issued by all waves;
+ * simds x clock / simd_cycles_per_inst is the chip's issue rate for that class. */
+enum {
+    RT_VALU_MIX_FMA = 0,        /* v_fma_f32 */
+    RT_VALU_MIX_MUL_ADD = 1,    /* v_mul_f32, v_add_f32 */
+    RT_VALU_MIX_PK_MUL_ADD = 2, /* v_pk_mul_f32, v_pk_add_f32 */
+    RT_VALU_MIX_PK_FMA = 3,     /* v_pk_fma_f32 */
+    RT_VALU_MIX_MIN_MAX = 4,    /* v_min_f32, v_max_f32 */
+    RT_VALU_MIX_CNDMASK = 5,    /* v_cndmask_b32 on a scalar mask */
+    RT_VALU_MIX_CMP = 6,        /* v_cmp_lt_f32 into a scalar mask */
+    RT_VALU_MIX_INT = 7,        /* v_add_u32, v_xor_b32, v_and_b32 */
+    RT_VALU_MIX_TRANS = 8,      /* v_rcp_f32, v_sqrt_f32 */
+    RT_VALU_MIX_BOX_STEP = 9,   /* the proportions of the persistent kernel's BOX step */
+    RT_VALU_MIX_MIN3_MAX3 = 10,  /* v_min3_f32, v_max3_f32 */
+    RT_VALU_MIX_CNDMASK_VCC = 11, /* v_cndmask_b32 on vcc (the short encoding) */
+    RT_VALU_MIX_CMP_VCC = 12,    /* v_cmp_lt_f32 into vcc (the short encoding) */
+    RT_VALU_MIX_MOV = 13,        /* v_mov_b32 */
+    RT_VALU_MIX_SHIFT_CVT = 14,  /* v_lshlrev_b32, v_cvt_f32_u32 */
+    RT_VALU_MIX_MUL_LO = 15,     /* v_mul_lo_u32 */
+    RT_VALU_MIX_DPP = 16,        /* v_add_u32 with a DPP row shift (the wave scans) */
+    RT_VALU_MIX_COUNT = 17
+};
+typedef struct rt_valu_probe {
+    uint64_t valu_insts;        /* vector instructions all waves issued inside their timed windows */
+    uint64_t waves;             /* waves launched, all resident at once */
+    uint64_t simds;             /* 4 x compute units */
+    double window_us;           /* length of a wave's timed window (median) */
+    double start_spread_us;     /* between the first and the last wave's start: must be << window_us */
+    double clock_mhz;           /* shader clock during the window (median over waves) */
+    double kernel_ms;           /* HIP-event time of the launch */
+    double wave_share_min;      /* least and most instructions one wave got, relative to an equal share */
+    double wave_share_max;
+    double simd_cycles_per_inst;
+} rt_valu_probe;
+int rt_probe_valu_issue(int device, int mix, uint32_t waves_per_simd, uint32_t duration_us, rt_valu_probe* out);
+
 /* Image files, in place of the reference's copy of binding 8 into the swapchain
  * (vulkan.rs:1045-1101).  Both take a host buffer of width*height RGBA floats, as
  * rt_read_present / rt_read_acc fill it, row 0 at the top.

@@ -71,6 +71,17 @@ class SchedStats(C.Structure):
     _fields_ = [("iterations", C.c_uint64 * 3), ("lanes", C.c_uint64 * 3), ("cycles", C.c_uint64 * 3), ("wait_cycles", C.c_uint64 * 3)]
 
 
+class ValuProbe(C.Structure):
+    _fields_ = [("valu_insts", C.c_uint64), ("waves", C.c_uint64), ("simds", C.c_uint64),
+                ("window_us", C.c_double), ("start_spread_us", C.c_double), ("clock_mhz", C.c_double),
+                ("kernel_ms", C.c_double), ("wave_share_min", C.c_double), ("wave_share_max", C.c_double),
+                ("simd_cycles_per_inst", C.c_double)]
+
+
+VALU_MIXES = ("fma", "mul_add", "pk_mul_add", "pk_fma", "min_max", "cndmask", "cmp", "int", "trans", "box_step",
+              "min3_max3", "cndmask_vcc", "cmp_vcc", "mov", "shift_cvt", "mul_lo", "dpp")
+
+
 class BvhParams(C.Structure):
     _fields_ = [("root_leaf_max", C.c_uint32), ("leaf_max", C.c_uint32), ("max_depth", C.c_uint32),
                 ("threads", C.c_int32)]
@@ -116,6 +127,7 @@ SIGNATURES = {
     "rt_synchronize": (_i32, [_vp]),
     "rt_selftest_fastmath_device": (_i32, [C.c_int, _P(C.c_uint64)]),
     "rt_selftest_rcp_device": (_i32, [C.c_int, _P(C.c_uint32)]),
+    "rt_probe_valu_issue": (_i32, [C.c_int, C.c_int, C.c_uint32, C.c_uint32, _P(ValuProbe)]),
     "rt_save_png": (_i32, [C.c_char_p, _vp, C.c_uint32, C.c_uint32]),
     "rt_save_exr": (_i32, [C.c_char_p, _vp, C.c_uint32, C.c_uint32, C.c_float]),
     "rt_read_acc": (_i32, [_vp, _vp, _sz]),

@@ -25,6 +25,7 @@
 #include <vector>
 
 #include "../../include/rt_hip.h"
+#include "host_scene.hpp"
 
 namespace {
 
@@ -171,8 +172,15 @@ __global__ void fit_boxes(const rt_vertex* v, const rt_tri* sorted, int n_leaves
     nodes[node] = out;
     while (node != 0u) {
         const uint32_t p = parent[node];
-        __threadfence();  // the box written above must be visible to whoever arrives second
-        if (atomicAdd(&arrived[p], 1u) == 0u) return;
+        // Release: the box written above must have left this XCD's L2 before the arrival counts
+        // (the explicit wait keeps the counter from overtaking the write-back).
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (__hip_atomic_fetch_add(&arrived[p], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
+        // Acquire: the sibling's box was written by another workgroup, maybe on another XCD; drop
+        // whatever stale copy of that line this CU's L1 holds before reading it.
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const rt_bvh a = nodes[left[p]], c = nodes[right[p]];
         for (int k = 0; k < 3; ++k) {
             b.lo[k] = a.bounding_box.min[k] < c.bounding_box.min[k] ? a.bounding_box.min[k] : c.bounding_box.min[k];
@@ -254,9 +262,7 @@ extern "C" int rt_create_bvh_device(int device, const rt_vertex* vertices, size_
                                     size_t n_triangles, uint32_t leaf_max, rt_bvh* nodes, size_t* n_nodes) {
     if (!vertices || !triangles || !n_nodes || n_triangles == 0 || leaf_max == 0) return RT_ERR_INVALID;
     if (n_triangles >= 0x7FFFFFFFull || n_vertices > 0xFFFFFFFFull) return RT_ERR_LIMIT;
-    for (size_t i = 0; i < n_triangles; ++i)
-        if (triangles[i].i0 >= n_vertices || triangles[i].i1 >= n_vertices || triangles[i].i2 >= n_vertices)
-            return RT_ERR_INVALID;
+    if (!rt::mesh_is_buildable(vertices, n_vertices, triangles, n_triangles)) return RT_ERR_INVALID;
     const uint32_t n = (uint32_t)n_triangles;
     const int n_leaves = (int)n;  // the full tree has one triangle per leaf
     const size_t total = 2 * (size_t)n_leaves - 1;  // upper bound on what survives the collapse

@@ -286,6 +286,15 @@ void emit_children(std::vector<rt_bvh>& out, const TNode* node, uint32_t index) 
 
 }  // namespace
 
+bool mesh_is_buildable(const rt_vertex* vertices, size_t n_vertices, const rt_tri* triangles, size_t n_triangles) {
+    for (size_t i = 0; i < n_triangles; ++i)
+        if (triangles[i].i0 >= n_vertices || triangles[i].i1 >= n_vertices || triangles[i].i2 >= n_vertices) return false;
+    for (size_t i = 0; i < n_vertices; ++i)
+        for (int k = 0; k < 3; ++k)
+            if (!std::isfinite(vertices[i].pos[k])) return false;
+    return true;
+}
+
 std::vector<rt_bvh> create_bvh(const rt_vertex* vertices, size_t n_vertices, rt_tri* triangles, size_t n_triangles,
                                const BvhBuildParams& params) {
     (void)n_vertices;

@@ -23,6 +23,11 @@ struct BvhBuildParams {
 // program/src/modules/mod.rs:6-36
 void parse_obj(const char* text, size_t len, std::vector<rt_vertex>& vertices, std::vector<rt_tri>& faces);
 
+// What every builder entry point checks before it builds: all indices in range and every vertex
+// position finite.  The reference panics on a NaN centroid (partial_cmp().unwrap(), bvh.rs:139);
+// here such a mesh is refused, since a NaN key would leave the sort's comparator no strict order.
+bool mesh_is_buildable(const rt_vertex* vertices, size_t n_vertices, const rt_tri* triangles, size_t n_triangles);
+
 // program/src/modules/bvh.rs:7-28.  Re-orders `triangles` in place and returns
 // the node array with LOCAL indices (node 0 is the root).
 std::vector<rt_bvh> create_bvh(const rt_vertex* vertices, size_t n_vertices, rt_tri* triangles,

@@ -64,9 +64,7 @@ int rt_parse_obj(const char* text, size_t len, rt_vertex* vertices, size_t* n_ve
 int rt_create_bvh(const rt_vertex* vertices, size_t n_vertices, rt_tri* triangles, size_t n_triangles,
                   const rt_bvh_params* params, rt_bvh* nodes, size_t* n_nodes) {
     if (!vertices || !triangles || !n_nodes || n_triangles == 0) return RT_ERR_INVALID;
-    for (size_t i = 0; i < n_triangles; ++i)
-        if (triangles[i].i0 >= n_vertices || triangles[i].i1 >= n_vertices || triangles[i].i2 >= n_vertices)
-            return RT_ERR_INVALID;
+    if (!mesh_is_buildable(vertices, n_vertices, triangles, n_triangles)) return RT_ERR_INVALID;
     std::vector<rt_bvh> out = create_bvh(vertices, n_vertices, triangles, n_triangles, to_params(params));
     if (nodes) {
         if (*n_nodes < out.size()) return RT_ERR_INVALID;
@@ -86,9 +84,7 @@ int rt_scene_builder_add_obj(rt_scene_builder* b, const char* text, size_t len, 
     std::vector<rt_vertex> v;
     std::vector<rt_tri> f;
     parse_obj(text, len, v, f);
-    if (f.empty()) return RT_ERR_INVALID;
-    for (const rt_tri& t : f)
-        if (t.i0 >= v.size() || t.i1 >= v.size() || t.i2 >= v.size()) return RT_ERR_INVALID;
+    if (f.empty() || !mesh_is_buildable(v.data(), v.size(), f.data(), f.size())) return RT_ERR_INVALID;
     b->sb.add_mesh(std::move(v), std::move(f), transforms, n_transforms, to_params(params));
     return RT_OK;
 }
@@ -97,9 +93,7 @@ int rt_scene_builder_add_mesh(rt_scene_builder* b, const rt_vertex* vertices, si
                               const rt_tri* triangles, size_t n_triangles, const rt_affine3a* transforms,
                               size_t n_transforms, const rt_bvh_params* params) {
     if (!b || !vertices || !triangles || n_triangles == 0 || (n_transforms && !transforms)) return RT_ERR_INVALID;
-    for (size_t i = 0; i < n_triangles; ++i)
-        if (triangles[i].i0 >= n_vertices || triangles[i].i1 >= n_vertices || triangles[i].i2 >= n_vertices)
-            return RT_ERR_INVALID;
+    if (!mesh_is_buildable(vertices, n_vertices, triangles, n_triangles)) return RT_ERR_INVALID;
     std::vector<rt_vertex> v(vertices, vertices + n_vertices);
     std::vector<rt_tri> f(triangles, triangles + n_triangles);
     b->sb.add_mesh(std::move(v), std::move(f), transforms, n_transforms, to_params(params));

@@ -1,12 +1,12 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): kernel-trace stats plus separate PMC passes of
-# `bench.py --steps 3 --warmup 1 --no-cpu-baseline`.  Output under gpurun_out/$1.
+# `bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras`.  Output under gpurun_out/$1.
 set -u
 TAG=${1:-prof}
 OUT=gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-BENCH="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline"
+BENCH="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $BENCH > "$OUT/bench_trace.json" 2> "$OUT/trace.err" || exit 1
 pass() {  # name, counters...
     local name=$1; shift
@@ -21,6 +21,7 @@ pass write WRITE_SIZE
 pass tcp TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_READ_sum TCP_TCC_WRITE_REQ_sum
 pass grbm GRBM_GUI_ACTIVE GRBM_COUNT
 pass sq3 SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM_RD SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_IFETCH SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_INSTS_BRANCH
+pass sq4 SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_IOPS
 pass sqc SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_REQ SQC_DCACHE_HITS SQC_DCACHE_MISSES
 pass ta TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum
 pass tcp2 TCP_GATE_EN1_sum TCP_GATE_EN2_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_PENDING_STALL_CYCLES_sum

@@ -13,7 +13,7 @@ import sys
 tag = sys.argv[1]
 src = os.path.join("gpurun_out", tag)
 os.makedirs("profiles", exist_ok=True)
-out = {"tag": tag, "command": "python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline"}
+out = {"tag": tag, "command": "python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras"}
 
 stats = glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv"))
 if stats:
@@ -22,7 +22,7 @@ if stats:
     out["kernel_stats"] = [{"name": r["Name"][:90], "calls": int(r["Calls"]), "avg_ms": float(r["AverageNs"]) / 1e6,
                             "pct": float(r["Percentage"])} for r in rows[:6]]
 
-KERNEL = "path_kernel_persistent<32, false>"
+KERNEL = "path_kernel_persistent<32, false, false>"
 pmc = {}
 for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
     if not os.path.isdir(d):
@@ -51,9 +51,25 @@ if "SQ_THREAD_CYCLES_VALU" in pmc:
     d["valu_lane_utilisation"] = pmc["SQ_THREAD_CYCLES_VALU"] / (64 * pmc["SQ_ACTIVE_INST_VALU"])
     d["wave_time_waiting_on_memory"] = pmc["SQ_WAIT_ANY"] / pmc["SQ_WAVE_CYCLES"]
     d["wave_time_issuing_valu"] = pmc["SQ_ACTIVE_INST_VALU"] / pmc["SQ_WAVE_CYCLES"]
-if "SQ_ACTIVE_INST_VALU" in pmc and "GRBM_GUI_ACTIVE" in pmc:
-    # a wave64 VALU instruction occupies its SIMD for 4 cycles; 256 CUs x 4 SIMDs; GRBM_GUI_ACTIVE sums 8 XCDs
-    d["valu_pipe_busy"] = pmc["SQ_ACTIVE_INST_VALU"] * 4.0 / 1024.0 / (pmc["GRBM_GUI_ACTIVE"] / 8.0)
+if "SQ_INSTS_VALU" in pmc and "GRBM_GUI_ACTIVE" in pmc:
+    # SIMD cycles of the launch: GRBM_GUI_ACTIVE sums the 8 XCDs; 256 CUs x 4 SIMDs.  A vector
+    # instruction takes the issue port of its SIMD for 2 cycles (full-rate classes) and many take
+    # their unit for 4 (the device micro-probe's table), so 2 x instructions is the floor of the
+    # pipe time and 4 x instructions its ceiling.  SQ_ACTIVE_INST_VALU is NOT pipe time: the probe
+    # shows it reads one quad-cycle per instruction whatever the instruction costs.
+    simd_cycles = pmc["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0
+    d["simd_cycles"] = simd_cycles
+    d["valu_issue_floor_frac"] = 2.0 * pmc["SQ_INSTS_VALU"] / simd_cycles
+    d["valu_issue_ceiling_frac"] = 4.0 * pmc["SQ_INSTS_VALU"] / simd_cycles
+    if "SQ_INSTS_VALU_ADD_F32" in pmc:
+        f32 = pmc["SQ_INSTS_VALU_ADD_F32"] + pmc["SQ_INSTS_VALU_MUL_F32"] + pmc["SQ_INSTS_VALU_FMA_F32"]
+        d["valu_f32_add_mul_fma_share"] = f32 / pmc["SQ_INSTS_VALU"]
+        d["valu_trans_share"] = pmc["SQ_INSTS_VALU_TRANS_F32"] / pmc["SQ_INSTS_VALU"]
+        d["valu_int_logic_share"] = pmc["SQ_INSTS_VALU_IOPS"] / pmc["SQ_INSTS_VALU"]
+        d["valu_cvt_share"] = pmc["SQ_INSTS_VALU_CVT"] / pmc["SQ_INSTS_VALU"]
+        # what no class counter sees: min / max / med3, compares, selects, moves, lane reads
+        d["valu_uncounted_share"] = 1.0 - (f32 + pmc["SQ_INSTS_VALU_TRANS_F32"] + pmc["SQ_INSTS_VALU_IOPS"]
+                                           + pmc["SQ_INSTS_VALU_CVT"]) / pmc["SQ_INSTS_VALU"]
 if "TCC_EA0_RDREQ_sum" in pmc:
     n32, n128 = pmc.get("TCC_EA0_RDREQ_32B_sum", 0), pmc.get("TCC_EA0_RDREQ_128B_sum", 0)
     n64 = pmc["TCC_EA0_RDREQ_sum"] - n32 - n128
@@ -86,9 +102,10 @@ if "bench_line_under_trace" in out and "l2_fabric_read_bytes" in d:
                "method": "TCC_EA0_RDREQ (32B/64B/128B split) and TCC_EA0_WRREQ (64B split) per dispatch of the "
                          "persistent kernel, separate rocprofv3 --pmc passes; equals 2 x FETCH_SIZE + WRITE_SIZE, "
                          "the gfx950 correction for 128-byte read requests tallied at 64 bytes",
-               "valu_pipe_busy": d.get("valu_pipe_busy"),
+               "valu_insts_per_launch": pmc.get("SQ_INSTS_VALU"),
+               "simd_cycles_per_launch": d.get("simd_cycles"),
                "source": f"profiles/{tag}_summary.json"}
-    json.dump(traffic, open(os.path.join("profiles", "traffic_bench.json"), "w"), indent=1)
+    json.dump(traffic, open(os.path.join("profiles", "counters_bench.json"), "w"), indent=1)
 path = os.path.join("profiles", f"{tag}_summary.json")
 json.dump(out, open(path, "w"), indent=1, sort_keys=True)
 print("wrote", path)

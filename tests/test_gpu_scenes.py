@@ -263,6 +263,59 @@ def test_gpu_built_linear_bvh_is_a_valid_tree_and_renders_like_the_oracle(leaf_m
     check_tree(same_n, 100, 1)
 
 
+def check_tree_vectorised(nodes, tris, pos, leaf_max):
+    """check_tree for trees too large to walk node by node in Python, and stricter: every node
+    reached exactly once from the root, leaves tile the triangle array, every leaf box is exactly
+    the bounds of its triangles and every internal box exactly the union of its children's."""
+    n_nodes, n_tris = len(nodes), len(tris)
+    internal = nodes["mode"] == 0
+    c1, c2 = nodes["c1"].astype(np.int64), nodes["c2"].astype(np.int64)
+    kids = np.concatenate([c1[internal], c2[internal]])
+    assert kids.min() >= 1 and kids.max() < n_nodes
+    refs = np.bincount(kids, minlength=n_nodes)
+    assert refs[0] == 0 and (refs[1:] == 1).all(), "a node with no parent or with two"
+    seen, frontier, depth = np.zeros(n_nodes, bool), np.array([0]), 0
+    while len(frontier):
+        assert not seen[frontier].any()
+        seen[frontier] = True
+        inner = frontier[internal[frontier]]
+        frontier = np.concatenate([c1[inner], c2[inner]])
+        depth += 1
+        assert depth <= 64
+    assert seen.all(), "nodes not reachable from the root"
+    leaves = np.flatnonzero(~internal)
+    order = np.argsort(c1[leaves], kind="stable")
+    first, last = c1[leaves][order], c2[leaves][order]
+    assert first[0] == 0 and last[-1] == n_tris - 1 and (first[1:] == last[:-1] + 1).all(), "leaves do not tile the triangles"
+    assert ((last - first) < leaf_max).all() and (last >= first).all()
+    corners = pos[tris.ravel()].reshape(n_tris, 3, 3)
+    tmin, tmax = corners.min(1), corners.max(1)
+    assert (np.minimum.reduceat(tmin, first) == nodes["min"][leaves][order]).all(), "a leaf box is not tight"
+    assert (np.maximum.reduceat(tmax, first) == nodes["max"][leaves][order]).all(), "a leaf box is not tight"
+    a, b = c1[internal], c2[internal]
+    assert (np.minimum(nodes["min"][a], nodes["min"][b]) == nodes["min"][internal]).all(), "an internal box is not the union"
+    assert (np.maximum(nodes["max"][a], nodes["max"][b]) == nodes["max"][internal]).all(), "an internal box is not the union"
+    return depth
+
+
+def test_gpu_built_bvh_of_a_million_triangles_is_exact_everywhere():
+    """The linear-BVH builder at the bench scene's size: boxes are merged bottom-up by whichever
+    thread reaches a node second, across workgroups and XCDs; a stale sibling box would give a
+    silently too-small parent.  Every box of the whole tree is compared with what it must hold,
+    on several builds in a row."""
+    verts, faces = S.terrain(n=700)
+    pos = np.asarray(verts, F)
+    faces = np.asarray(faces, np.uint32)
+    assert len(faces) >= 970_000
+    for leaf_max in (4, 1, 16):
+        tris, nodes = S.create_bvh_gpu(verts, faces, leaf_max=leaf_max)
+        assert len(tris) == len(faces)
+        depth = check_tree_vectorised(nodes, tris, pos, leaf_max)
+        assert depth <= 64
+    key = lambda t: np.sort(t[:, 0].astype(np.uint64) << np.uint64(42) | t[:, 1].astype(np.uint64) << np.uint64(21) | t[:, 2].astype(np.uint64))
+    assert (key(tris) == key(faces)).all(), "the triangles are not a permutation of the input"
+
+
 def parse_obj(name):
     data = S._resource(name).encode()
     lib = L.load()

@@ -300,6 +300,18 @@ def test_scene_builder_rejects_bad_input():
         b.add_mesh(np.zeros((3, 3), F), np.array([[0, 1, 5]], np.uint32), [ident])  # index out of range
     with pytest.raises(L.RtError):
         b.add_obj_file("v 0 0 0\n", [ident])  # no faces
+    # a vertex that is not finite: the reference panics when it sorts the centroids (bvh.rs:139)
+    for bad in (np.nan, np.inf):
+        v = np.array([[0, 0, 0], [1, 0, 0], [0, 1, bad]], F)
+        with pytest.raises(L.RtError):
+            b.add_mesh(v, np.array([[0, 1, 2]], np.uint32), [ident])
+        vv = np.zeros(3, S.VERTEX_DT)
+        vv["pos"] = v
+        tt, n = np.array([[0, 1, 2]], np.uint32), C.c_size_t(0)
+        assert lib.rt_create_bvh(S._ptr(vv), 3, S._ptr(tt), 1, None, None, C.byref(n)) == L.RT_ERR_INVALID
+        assert lib.rt_create_bvh_device(0, S._ptr(vv), 3, S._ptr(tt), 1, 4, None, C.byref(n)) == L.RT_ERR_INVALID
+    with pytest.raises(L.RtError):
+        b.add_obj_file("v 0 0 0\nv 1 0 0\nv 0 nan 0\nf 1 2 3\n", [ident])
 
 
 # ------------------------------------------------------- arithmetic self-test ------
