@@ -6,6 +6,7 @@ library has not been built -- there is no Python or CPU stand-in for it.
 """
 import ctypes as C
 import os
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "librt_hip.so")
@@ -175,6 +176,14 @@ def load():
         raise RuntimeError(
             f"{LIB_PATH} is missing: build it with `make -C ray_tracing_amd/csrc` "
             "(or __graft_entry__.build()).  There is no fallback implementation.")
+    # PyTorch ships a HIP runtime of its own.  A process that uses both must end up with ONE
+    # runtime: loaded after this library's, PyTorch's finds "no HIP GPUs".  So when PyTorch is
+    # installed it goes first; this library then binds to the runtime already in the process.
+    if "torch" not in sys.modules:
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)
