@@ -314,7 +314,7 @@ def main():
         try:
             with open(os.path.join(ROOT, "profiles", "counters_bench.json")) as f:
                 tr = json.load(f)
-            if tr["workload"] == workload and tr["n_gpus"] == world:
+            if tr["workload"] == workload and tr["n_gpus"] == 1:
                 return tr
         except (OSError, KeyError, ValueError):
             pass
@@ -333,9 +333,13 @@ def main():
         if L.load().rt_probe_valu_issue(device_index, L.VALU_MIXES.index("mul_add"), 4, 2000, C.byref(probe)) == 0:
             peak = probe.simds * probe.clock_mhz * 1e6 / probe.simd_cycles_per_inst / 1e9
         insts = prof.get("valu_insts_per_launch")
+        traffic = prof.get("traffic_bytes_per_launch")
+        if insts and world > 1:
+            # this rank's share of a launch profiled on one GPU: instructions and bytes go with the rays
+            share = counted["rays"] / prof["rays_per_launch"]
+            insts, traffic = insts * share, traffic * share
         achieved = insts / (kernel_ms * 1e-3) / 1e9 if insts else None
         rank_bytes = float(algorithmic_bytes(counted, n_inst))
-        traffic = prof.get("traffic_bytes_per_launch")
         out = {
             "metric": "Mrays/s (primary+secondary)", "value": total_rays / elapsed / 1e6, "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,

@@ -145,7 +145,11 @@ bool build_gpu_scene(const rt_scene_info& info, const rt_vertex* vertices, size_
     out.fast_div = true;
     for (size_t i = 0; i < n_bvh; ++i)
         for (int k = 0; k < 3; ++k)
-            if (!div_term_ok(bvh[i].bounding_box.min[k]) || !div_term_ok(bvh[i].bounding_box.max[k])) out.fast_div = false;
+            // an inverted box also rules the shortcut out: it picks each slab's entry plane by the sign of
+            // the ray direction, which is the nearer of the two only when min <= max
+            if (!div_term_ok(bvh[i].bounding_box.min[k]) || !div_term_ok(bvh[i].bounding_box.max[k]) ||
+                !(bvh[i].bounding_box.min[k] <= bvh[i].bounding_box.max[k]))
+                out.fast_div = false;
 
     std::vector<uint32_t> dense(n_bvh, 0);
     uint32_t n_internal = 0;

@@ -574,19 +574,21 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((COUNT |
                 const bool desc = phase == ST_DESC;
                 const bool popping = phase == ST_POP;
                 const bool act = desc || popping;
-                const f2 lox = it0.xy, hix = it0.zw, loy = it1.xy, hiy = it1.zw, loz = it2.xy, hiz = it2.zw;
+                const float lox[2] = {it0.x, it0.y}, hix[2] = {it0.z, it0.w};
+                const float loy[2] = {it1.x, it1.y}, hiy[2] = {it1.z, it1.w};
+                const float loz[2] = {it2.x, it2.y}, hiz[2] = {it2.z, it2.w};
                 const uint32_t a0 = __float_as_uint(it3.x), a1 = __float_as_uint(it3.y);
                 const uint32_t b0 = __float_as_uint(it3.z), b1 = __float_as_uint(it3.w);
-                const f2 px = dpx.xx, py = dpy.xx, pz = dpz.xx;
+                const float px = dpx.x, py = dpy.x, pz = dpz.x;
                 // BoundingBox::center (shared/src/lib.rs:155-157) and hit.rs:92-100
-                const f2 ex = (lox + hix) * 0.5f - px, ey = (loy + hiy) * 0.5f - py, ez = (loz + hiz) * 0.5f - pz;
-                const f2 d2 = (ex * ex + ey * ey) + ez * ez;
-                // Pinned here (an empty asm the compiler may not move): the ordering shares the
-                // splatted ray origin with the slab arithmetic below, and the splats only fold
-                // into the packed instructions' operand selectors within one basic block.
-                float d2_0 = d2.x, d2_1 = d2.y;
-                asm volatile("" : "+v"(d2_0), "+v"(d2_1));
-                const bool first_is_1 = d2_0 < d2_1;
+                float d2c[2];
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const float ex = (lox[k] + hix[k]) * 0.5f - px, ey = (loy[k] + hiy[k]) * 0.5f - py,
+                                ez = (loz[k] + hiz[k]) * 0.5f - pz;
+                    d2c[k] = (ex * ex + ey * ey) + ez * ez;
+                }
+                const bool first_is_1 = d2c[0] < d2c[1];
                 // the child tested "now" is child 0.  Every condition of this step is computed into a
                 // named flag first and the flags are then combined: the step is meant to be one
                 // straight run of instructions, not a tree of branches.
@@ -602,11 +604,25 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((COUNT |
                 // for every lane; quotients through the cached reciprocal need the lane's operands
                 // in range; approximate quotients also need every comparison to be clear-cut.
                 // One lane outside a premise moves the whole wave to the next, dearer form.
-                const f2 rx = splat(rcx), ry = splat(rcy), rz = splat(rcz);
-                const f2 nx = (lox - px) * rx, ny = (loy - py) * ry, nz = (loz - pz) * rz;
-                const f2 fx = (hix - px) * rx, fy = (hiy - py) * ry, fz = (hiz - pz) * rz;
-                const f2 tn = vmax(vmax(vmin(nx, fx), vmin(ny, fy)), vmin(nz, fz));
-                const f2 tf = vmin(vmin(vmax(nx, fx), vmax(ny, fy)), vmax(nz, fz));
+                // The approximate form picks each slab's entry and exit plane by the sign of the
+                // reciprocal (a bitwise select) instead of ordering the two quotients: the same values
+                // whenever min <= max and the reciprocal is finite, which the premises include.
+                const uint32_t mx = (uint32_t)((int32_t)__float_as_uint(rcx) >> 31),
+                               my = (uint32_t)((int32_t)__float_as_uint(rcy) >> 31),
+                               mz = (uint32_t)((int32_t)__float_as_uint(rcz) >> 31);
+                auto pick = [](uint32_t m, float when_set, float when_clear) {
+                    return __uint_as_float((__float_as_uint(when_set) & m) | (__float_as_uint(when_clear) & ~m));
+                };
+                float tn_[2], tf_[2];
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const float nx = (pick(mx, hix[k], lox[k]) - px) * rcx, fx = (pick(mx, lox[k], hix[k]) - px) * rcx;
+                    const float ny = (pick(my, hiy[k], loy[k]) - py) * rcy, fy = (pick(my, loy[k], hiy[k]) - py) * rcy;
+                    const float nz = (pick(mz, hiz[k], loz[k]) - pz) * rcz, fz = (pick(mz, loz[k], hiz[k]) - pz) * rcz;
+                    tn_[k] = __builtin_fmaxf(__builtin_fmaxf(nx, ny), nz);
+                    tf_[k] = __builtin_fminf(__builtin_fminf(fx, fy), fz);
+                }
+                const f2 tn = {tn_[0], tn_[1]}, tf = {tf_[0], tf_[1]};
                 const SlabApprox s0 = {tn.x, tf.x}, s1 = {tn.y, tf.y};
                 const bool amb0 = slab_ambiguous(s0, rec.t), amb1 = slab_ambiguous(s1, rec.t);
                 // a descent needs both children clear-cut, a pop only the child it looks at
@@ -617,8 +633,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((COUNT |
                 if (__ballot(amb) != 0ull) {
                     const bool out_of_range = act && !rcp_ok;
                     const bool all_fast = __ballot(out_of_range) == 0ull;
-                    const float4 lo0 = make_float4(lox.x, loy.x, loz.x, 0.0f), hi0 = make_float4(hix.x, hiy.x, hiz.x, 0.0f);
-                    const float4 lo1 = make_float4(lox.y, loy.y, loz.y, 0.0f), hi1 = make_float4(hix.y, hiy.y, hiz.y, 0.0f);
+                    const float4 lo0 = make_float4(lox[0], loy[0], loz[0], 0.0f), hi0 = make_float4(hix[0], hiy[0], hiz[0], 0.0f);
+                    const float4 lo1 = make_float4(lox[1], loy[1], loz[1], 0.0f), hi1 = make_float4(hix[1], hiy[1], hiz[1], 0.0f);
                     if (all_fast) {
                         DirRcp r;
                         r.x = rcx;

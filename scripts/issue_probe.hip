@@ -14,35 +14,36 @@ template <int ID> __device__ __forceinline__ void body(float (&r)[16], float a, 
         _Pragma("unroll") for (int j = 0; j < 4; ++j) { _Pragma("unroll") for (int k = 0; k < 16; ++k) { STMT; } }    \
     }
 
-SNIPPET(0, "", asm volatile("v_cmp_lt_f32_e32 vcc, %0, %1\n\tv_cndmask_b32_e32 %0, %0, %2, vcc\n\tv_cndmask_b32_e32 %3, %3, %2, vcc" : "+v"(r[k]), "+v"(r[(k+1)&15]) : "v"(a), "v"(b) : "vcc"))
-SNIPPET(1, "", asm volatile("v_cmp_lt_f32_e32 vcc, %0, %2\n\tv_cndmask_b32_e32 %0, %0, %3, vcc\n\tv_cndmask_b32_e32 %1, %1, %3, vcc\n\tv_cndmask_b32_e32 %4, %4, %3, vcc\n\tv_cndmask_b32_e32 %5, %5, %3, vcc" : "+v"(r[k]), "+v"(r[(k+1)&15]) , "+v"(r[(k+2)&15]), "+v"(r[(k+3)&15]): "v"(a), "v"(b) : "vcc"))
-SNIPPET(2, "", asm volatile("v_cmp_lt_f32_e64 %6, %0, %4\n\tv_cndmask_b32_e64 %0, %0, %5, %6\n\tv_cndmask_b32_e64 %1, %1, %5, %6\n\tv_cndmask_b32_e64 %2, %2, %5, %6\n\tv_cndmask_b32_e64 %3, %3, %5, %6" : "+v"(r[k]), "+v"(r[(k+1)&15]) , "+v"(r[(k+2)&15]), "+v"(r[(k+3)&15]): "v"(a), "v"(b), "s"(m0)))
-SNIPPET(3, "", asm volatile("v_cmp_lt_f32_e32 vcc, %0, %1\n\tv_mul_f32_e32 %3, %3, %1\n\tv_cndmask_b32_e32 %0, %0, %2, vcc" : "+v"(r[k]), "+v"(r[(k+1)&15]) : "v"(a), "v"(b) : "vcc"))
-SNIPPET(4, "", asm volatile("v_cmp_lt_f32_e32 vcc, %0, %1\n\tv_mul_f32_e32 %3, %3, %1\n\tv_mul_f32_e32 %3, %3, %1\n\tv_mul_f32_e32 %3, %3, %1\n\tv_mul_f32_e32 %3, %3, %1\n\tv_cndmask_b32_e32 %0, %0, %2, vcc" : "+v"(r[k]), "+v"(r[(k+1)&15]) : "v"(a), "v"(b) : "vcc"))
-SNIPPET(5, "", asm volatile("s_mov_b64 vcc, %2\n\tv_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(r[k]) : "v"(a), "s"(m0) : "vcc"))
-SNIPPET(6, "", asm volatile("v_min_f32_e32 %0, %0, %1\n\tv_mul_f32_e32 %2, %2, %1" : "+v"(r[k]), "+v"(r[(k+1)&15]) : "v"(a)))
-SNIPPET(7, "", asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(*(double*)&r[(2*k)&15]) : "v"(*(double*)&r[(2*k+2)&15])))
-SNIPPET(8, "", asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(r[k]) : "v"(a), "v"(b)))
-SNIPPET(9, "", asm volatile("v_cmp_lt_f32_e32 vcc, %0, %1\n\tv_cndmask_b32_e64 %0, %0, %2, vcc\n\tv_cndmask_b32_e64 %3, %3, %2, vcc" : "+v"(r[k]), "+v"(r[(k+1)&15]) : "v"(a), "v"(b) : "vcc"))
-SNIPPET(10, "", asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(r[k]) : "v"(a), "v"(b)))
-SNIPPET(11, "", asm volatile("v_fma_f32 %0, %0, %1, -%2" : "+v"(r[k]) : "v"(a), "v"(b)))
-SNIPPET(12, "", asm volatile("v_fma_f32 %0, %0, %1, 1.0" : "+v"(r[k]) : "v"(a)))
-SNIPPET(13, "", asm volatile("v_mul_f32_e32 %0, 0.5, %0" : "+v"(r[k])))
-SNIPPET(14, "", asm volatile("v_mul_f32_e32 %0, 0x3fc00000, %0" : "+v"(r[k])))
-SNIPPET(15, "", asm volatile("v_sub_f32_e64 %0, %0, |%1|" : "+v"(r[k]): "v"(a)))
-SNIPPET(16, "", asm volatile("v_subrev_f32_e32 %0, %1, %0" : "+v"(r[k]): "v"(a)))
-SNIPPET(17, "", asm volatile("v_or_b32_e32 %0, %1, %0" : "+v"(r[k]): "v"(a)))
-SNIPPET(18, "", asm volatile("v_sub_u32_e32 %0, %1, %0" : "+v"(r[k]): "v"(a)))
-SNIPPET(19, "", asm volatile("v_cmp_eq_u32_e32 vcc, %0, %1" :: "v"(r[k]), "v"(a) : "vcc"))
-SNIPPET(20, "", asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(r[k]): "v"(a), "v"(b)))
-SNIPPET(21, "", asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(r[k]): "v"(a), "v"(b)))
-SNIPPET(22, "", asm volatile("v_lshrrev_b32_e32 %0, 1, %0" : "+v"(r[k])))
-SNIPPET(23, "", asm volatile("v_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(r[k]) : "v"(a)))
+SNIPPET(0, "", asm volatile("v_mul_f32_e32 %0, %0, %1" : "+v"(r[0]) : "v"(a)))
+SNIPPET(1, "", asm volatile("v_mul_f32_e32 %0, %0, %1" : "+v"(r[k & 1]) : "v"(a)))
+SNIPPET(2, "", asm volatile("v_mul_f32_e32 %0, %0, %1" : "+v"(r[k & 3]) : "v"(a)))
+SNIPPET(3, "", asm volatile("v_min_f32_e32 %0, %0, %1" : "+v"(r[0]) : "v"(a)))
+SNIPPET(4, "", asm volatile("v_min_f32_e32 %0, %0, %1" : "+v"(r[k & 1]) : "v"(a)))
+SNIPPET(5, "", asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(r[0]) : "v"(a), "s"(m0)))
+SNIPPET(6, "", asm volatile("v_cmp_lt_f32_e64 %2, %0, %1\n\ts_nop 1\n\tv_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(r[0]) : "v"(a), "s"(m0)))
+SNIPPET(7, "", asm volatile("v_cmp_lt_f32_e64 %2, %0, %1\n\ts_nop 1\n\tv_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(r[k&3]) : "v"(a), "s"(m0)))
+SNIPPET(8, "", asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(*(double*)&r[0]) : "v"(*(double*)&r[2])))
+SNIPPET(9, "", asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(r[0]) : "v"(a), "v"(b)))
+SNIPPET(10, "", asm volatile("v_add_u32_e32 %0, %0, %1" : "+v"(r[0]) : "v"(a)))
+SNIPPET(11, "", asm volatile("v_mul_f32_e32 %0, %0, %1\n\tv_min_f32_e32 %0, %0, %2" : "+v"(r[0]) : "v"(a), "v"(b)))
+SNIPPET(12, "", asm volatile("v_cmp_lt_f32_e32 vcc, %0, %1\n\ts_nop 1\n\tv_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(r[0]) : "v"(a) : "vcc"))
+SNIPPET(13, "", asm volatile("v_cmp_lt_f32_e32 vcc, %0, %2\n\ts_nop 1\n\tv_cndmask_b32_e32 %0, %0, %2, vcc\n\tv_cndmask_b32_e32 %1, %1, %2, vcc" : "+v"(r[k&7]), "+v"(r[8+(k&7)]) : "v"(a) : "vcc"))
+SNIPPET(14, "", asm volatile("v_cmp_lt_f32_e32 vcc, %0, %3\n\ts_nop 1\n\tv_cndmask_b32_e32 %0, %0, %3, vcc\n\tv_cndmask_b32_e32 %1, %1, %3, vcc\n\tv_cndmask_b32_e32 %2, %2, %3, vcc" : "+v"(r[k&3]), "+v"(r[4+(k&3)]), "+v"(r[8+(k&3)]) : "v"(a) : "vcc"))
+SNIPPET(15, "", asm volatile("s_and_b64 vcc, %2, %3\n\ts_nop 1\n\tv_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(r[k]) : "v"(a), "s"(m0), "s"(m0^5) : "vcc"))
+SNIPPET(16, "", asm volatile("s_and_b64 vcc, %2, %3\n\tv_mul_f32_e32 %4, %4, %1\n\tv_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(r[k&7]) : "v"(a), "s"(m0), "s"(m0^5), "v"(r[8+(k&7)]) : "vcc"))
+SNIPPET(17, "", asm volatile("s_and_b64 %3, %2, %3\n\ts_nop 1\n\tv_cndmask_b32_e64 %0, %0, %1, %3" : "+v"(r[k]) : "v"(a), "s"(m0), "s"(m0^5)))
+SNIPPET(18, "", asm volatile("s_and_saveexec_b64 %2, %3\n\tv_mov_b32_e32 %0, %1\n\ts_or_b64 exec, exec, %2" : "+v"(r[k]) : "v"(a), "s"(m0^9), "s"(m0)))
+SNIPPET(19, "", asm volatile("s_and_saveexec_b64 %3, %4\n\tv_mov_b32_e32 %0, %2\n\tv_mov_b32_e32 %1, %2\n\ts_or_b64 exec, exec, %3" : "+v"(r[k&7]), "+v"(r[8+(k&7)]) : "v"(a), "s"(m0^9), "s"(m0)))
+SNIPPET(20, "", asm volatile("s_mov_b64 exec, %2\n\tv_mov_b32_e32 %0, %1\n\ts_mov_b64 exec, -1" : "+v"(r[k]) : "v"(a), "s"(m0)))
+SNIPPET(21, "", asm volatile("v_ashrrev_i32_e32 %0, 31, %0" : "+v"(r[k])))
+SNIPPET(22, "", asm volatile("v_lshlrev_b32_e32 %0, 6, %0" : "+v"(r[k])))
+SNIPPET(23, "", asm volatile("v_cmp_lt_f32_e64 %1, %0, %2\n\tv_cmp_gt_f32_e64 %3, %0, %2\n\ts_and_b64 %1, %1, %3" : : "v"(r[k]), "s"(m0), "v"(a), "s"(m0^7)))
 constexpr int kN = 24;
-const char* kNames[kN] = {"cmp32+2cnd32 (3)", "cmp32+4cnd32 (5)", "cmp64+4cnd64 (5)", "cmp32,mul,cnd32 (3)", "cmp32,4mul,cnd32 (6)",
-  "s_mov vcc + cnd32 (1)", "min+mul (2)", "pk_mul", "max3", "cmp32+2cnd64vcc (3)", "fma", "fma negmod", "fma const", "mul inline const",
-  "mul literal", "sub_e64 abs", "subrev", "or", "sub_u32", "cmp_eq_u32 e32", "bitop3", "add3_u32", "lshrrev", "mov_dpp"};
-const int kPerStmt[kN] = {3,5,5,3,6,1,2,1,1,3,1,1,1,1,1,1,1,1,1,1,1,1,1,1};
+const char* kNames[kN] = {"mul dep chain 1", "mul dep chain 2", "mul dep chain 4", "min dep chain 1", "min dep chain 2", "cnd64 dep chain",
+  "cmp64,nop,cnd64 dep (2)", "cmp64,nop,cnd64 4 chains (2)", "pk_mul dep", "fma dep", "add_u32 dep", "mul,min dep (2)", "cmp32,nop,cnd32 dep (2)",
+  "cmp32,nop,2cnd32 (3)", "cmp32,nop,3cnd32 (4)", "s_and vcc,nop,cnd32 (1v)", "s_and vcc,mul,cnd32 (2v)", "s_and,nop,cnd64 (1v)",
+  "saveexec,mov,or (1v)", "saveexec,2mov,or (2v)", "s_mov exec,mov,restore (1v)", "ashrrev 31", "lshlrev 6", "2cmp64+s_and (2v)"};
+const int kPerStmt[kN] = {1,1,1,1,1,1,2,2,1,1,1,2,2,3,4,1,2,1,1,2,1,1,1,2};
 
 template <int ID>
 __global__ __launch_bounds__(256) void probe(uint32_t ticks, unsigned long long* stamps, float* sink) {

@@ -103,6 +103,7 @@ if "bench_line_under_trace" in out and "l2_fabric_read_bytes" in d:
                          "persistent kernel, separate rocprofv3 --pmc passes; equals 2 x FETCH_SIZE + WRITE_SIZE, "
                          "the gfx950 correction for 128-byte read requests tallied at 64 bytes",
                "valu_insts_per_launch": pmc.get("SQ_INSTS_VALU"),
+               "rays_per_launch": line["config"]["rays_per_step"],
                "simd_cycles_per_launch": d.get("simd_cycles"),
                "source": f"profiles/{tag}_summary.json"}
     json.dump(traffic, open(os.path.join("profiles", "counters_bench.json"), "w"), indent=1)
