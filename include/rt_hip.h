@@ -173,6 +173,12 @@ typedef struct rt_sched_stats {
     uint64_t lanes[3];
     uint64_t cycles[3];
     uint64_t wait_cycles[3]; /* the part of `cycles` spent waiting for the step's prefetched item */
+    /* the part of `cycles` spent waiting for outstanding memory operations at marked places:
+     * 0 control: the fetched pixel's accumulator; 1 control: an instance record (scalar loads);
+     * 2 control: what shading loaded; 3 box: the popped stack entry; 4 triangle: who works for
+     * whom (LDS); 5 triangle: the owner's ray and the triangle record; 6 triangle: the exact
+     * fallback's triangle; 7 triangle: the folded results (LDS atomics) */
+    uint64_t site_wait_cycles[8];
 } rt_sched_stats;
 int rt_get_sched_stats(rt_ctx* ctx, rt_sched_stats* out);
 int rt_reset_stats(rt_ctx* ctx);

@@ -69,7 +69,8 @@ class Stats(C.Structure):
 
 
 class SchedStats(C.Structure):
-    _fields_ = [("iterations", C.c_uint64 * 3), ("lanes", C.c_uint64 * 3), ("cycles", C.c_uint64 * 3), ("wait_cycles", C.c_uint64 * 3)]
+    _fields_ = [("iterations", C.c_uint64 * 3), ("lanes", C.c_uint64 * 3), ("cycles", C.c_uint64 * 3), ("wait_cycles", C.c_uint64 * 3),
+                ("site_wait_cycles", C.c_uint64 * 8)]
 
 
 class ValuProbe(C.Structure):

@@ -179,7 +179,8 @@ class App:
     def sched_stats(self):
         s = L.SchedStats()
         self._check(self._lib.rt_get_sched_stats(self._ctx, C.byref(s)))
-        return {"iterations": list(s.iterations), "lanes": list(s.lanes), "cycles": list(s.cycles), "wait_cycles": list(s.wait_cycles)}
+        return {"iterations": list(s.iterations), "lanes": list(s.lanes), "cycles": list(s.cycles), "wait_cycles": list(s.wait_cycles),
+                "site_wait_cycles": list(s.site_wait_cycles)}
 
     def reset_stats(self):
         self._check(self._lib.rt_reset_stats(self._ctx))

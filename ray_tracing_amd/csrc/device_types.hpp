@@ -131,6 +131,8 @@ struct DevStats {
     // wave iterations that ran a control / box / triangle step,
     // the lanes that took part in them and the cycles they took
     unsigned long long iters[3], lanes[3], cycles[3], wait_cycles[3];
+    // cycles waves spent waiting for memory (global, LDS, scalar) at marked places of the steps
+    unsigned long long site_wait[8];
 };
 
 // Work queues of the persistent kernel: 8 ranges of 64-pixel items (8x8 tiles),

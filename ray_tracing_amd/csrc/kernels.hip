@@ -218,6 +218,15 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((COUNT |
     unsigned long long n_rays = 0, n_box = 0, n_internal = 0, n_tri = 0, n_paths = 0;
     unsigned long long sched_iters[3] = {0, 0, 0}, sched_lanes[3] = {0, 0, 0}, sched_cycles[3] = {0, 0, 0},
                        sched_wait[3] = {0, 0, 0};  // wave-uniform
+    unsigned long long site_wait[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // wave-uniform, profile only
+    // profile only: wait here for every outstanding memory operation and book the time to `site`
+    auto wait_site = [&](int site) {
+        if (COUNT) {
+            const unsigned long long t0 = __builtin_readcyclecounter();
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            site_wait[site] += __builtin_readcyclecounter() - t0;
+        }
+    };
 
     // what names node record `a` / where a named item and a triangle's test record live
     auto node_item = [&](uint32_t a) -> uint32_t { return BIG ? sc.node_unit + a : sc.node_off + a * 64u; };
@@ -311,6 +320,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((COUNT |
                         phase = ST_DEAD;
                     }
                 }
+                wait_site(0);
             }
             // Two rounds of: (1) the instance loop of trace_ray (trace.rs:76-94) for every lane that
             // stands between two instances, (2) the rest of trace_ray and whatever follows it for
@@ -335,6 +345,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((COUNT |
                     const float blox = I->root.lox[0], bloy = I->root.loy[0], bloz = I->root.loz[0];
                     const float bhix = I->root.hix[0], bhiy = I->root.hiy[0], bhiz = I->root.hiz[0];
                     const uint32_t a = I->root.a[0], b = I->root.b[0];
+                    wait_site(1);
                     const bool is_internal = b == kInternalTag, has_tris = a <= b;
                     // First from the hardware's approximate reciprocals (three instructions): most
                     // lanes miss most root boxes, clearly.  Only when some lane hits one, or cannot
@@ -400,6 +411,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((COUNT |
                             n_tri += rec.triangle_tests;
                         }
                         int state = shade(sc, cam, rec, ray, seed, color);
+                        wait_site(2);
                         seg += 1;
                         if (state == STATE_RAY && seg < cam.depth) {
                             ctl = CT_START_SEGMENT;
@@ -473,7 +485,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((COUNT |
                 asm volatile("" ::: "memory");
                 if (n_proc != 0u) tmp[excl] = lane + 1u;
                 asm volatile("" ::: "memory");
-                const uint32_t own1 = wave_incl_max(tmp[lane]);
+                uint32_t tmp_mine = tmp[lane];
+                wait_site(4);
+                const uint32_t own1 = wave_incl_max(tmp_mine);
                 const uint32_t o = own1 != 0u ? own1 - 1u : lane;
                 // the owner's first pair, pair count and culling rule travel in one word
                 const uint32_t o_info = (uint32_t)__shfl((int)(excl | (n_proc << 8) | (cull ? 1u << 16 : 0u)), (int)o, 64);
@@ -494,6 +508,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((COUNT |
                 const f2 wy = {__shfl(dpy.x, (int)o, 64), __shfl(dpy.y, (int)o, 64)};
                 const f2 wz = {__shfl(dpz.x, (int)o, 64), __shfl(dpz.y, (int)o, 64)};
                 const bool w_cull = (o_info & (1u << 16)) != 0u;
+                wait_site(5);
                 const V3 wpos = v3(wx.x, wy.x, wz.x), wdir = v3(wx.y, wy.y, wz.y);
                 // (n . pos, n . dir) in one go: dot's order, (x + y) + z, in both halves
                 const f2 np_nd = (splat(b0.x) * wx + splat(b0.y) * wy) + splat(b0.z) * wz;
@@ -515,6 +530,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((COUNT |
                         const float4* fp = reinterpret_cast<const float4*>(&sc.tris[tri]);
                         t = triangle_ray_intersect(fp[0], fp[1], fp[2], fp[3].x, wpos, wdir, kEps, RT_INF, w_cull);
                     }
+                    wait_site(6);
                 }
                 // What an owner keeps of its results is what the sequential loop would keep: a
                 // candidate (a finite distance) is accepted when it is not beyond the best so far,
@@ -537,6 +553,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((COUNT |
                     if (cand) atomicMin(&slot[o], ((unsigned long long)__float_as_uint(t) << 32) | (0xFFFFFFFFu - kw));
                     asm volatile("" ::: "memory");
                     const unsigned long long kept = slot[lane];
+                    wait_site(7);
                     const bool any = owner && kept != ~0ull;
                     best = any ? __uint_as_float((uint32_t)(kept >> 32)) : best;
                     best_k = any ? 0xFFFFFFFFu - (uint32_t)kept : best_k;
@@ -678,6 +695,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((COUNT |
             const bool inst_end = finished && empty;
             uint32_t ref = 0;
             if (pop) ref = stack[(sp - 1u) * kBlock];
+            wait_site(3);
             sp -= pop ? 1u : 0u;
             inst += inst_end ? 1u : 0u;
             phase = pop ? (uint32_t)ST_POP : inst_end ? (uint32_t)ST_CONTROL : phase;
@@ -702,6 +720,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((COUNT |
             atomicAdd(&fr.stats->cycles[k], sched_cycles[k]);
             atomicAdd(&fr.stats->wait_cycles[k], sched_wait[k]);
         }
+        for (int k = 0; k < 8; ++k) atomicAdd(&fr.stats->site_wait[k], site_wait[k]);
     }
 }
 

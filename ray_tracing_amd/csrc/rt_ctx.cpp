@@ -669,6 +669,7 @@ int rt_get_sched_stats(rt_ctx* c, rt_sched_stats* out) {
         out->cycles[k] = s.cycles[k];
         out->wait_cycles[k] = s.wait_cycles[k];
     }
+    for (int k = 0; k < 8; ++k) out->site_wait_cycles[k] = s.site_wait[k];
     return RT_OK;
 }
 
