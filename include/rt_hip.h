@@ -90,7 +90,9 @@ enum {
     /* How the cost-sorted tiles are shared out over the 8 queues: 1 = dealt in turn, 0 = a
      * contiguous band of the canvas per queue, -1 (default) = dealt for launches of up to four
      * frames, banded for longer ones. */
-    RT_OPT_TILE_DEAL = 12
+    RT_OPT_TILE_DEAL = 12,
+    /* Pooled kernel (RT_OPT_PIPELINE 2): ray slots each wave keeps in flight, 64..192; 0 (default) = 192. */
+    RT_OPT_POOL_SLOTS = 13
 };
 
 /* ---- lifecycle: vulkan::App::create / App::destroy (vulkan.rs:124-168, 374) ---- */
@@ -179,6 +181,8 @@ typedef struct rt_sched_stats {
      * whom (LDS); 5 triangle: the owner's ray and the triangle record; 6 triangle: the exact
      * fallback's triangle; 7 triangle: the folded results (LDS atomics) */
     uint64_t site_wait_cycles[8];
+    /* the pooled kernel's SHADE steps (RT_OPT_PIPELINE 2): iterations, slots shaded, cycles */
+    uint64_t shade_iterations, shade_slots, shade_cycles;
 } rt_sched_stats;
 int rt_get_sched_stats(rt_ctx* ctx, rt_sched_stats* out);
 int rt_reset_stats(rt_ctx* ctx);

@@ -70,7 +70,8 @@ class Stats(C.Structure):
 
 class SchedStats(C.Structure):
     _fields_ = [("iterations", C.c_uint64 * 3), ("lanes", C.c_uint64 * 3), ("cycles", C.c_uint64 * 3), ("wait_cycles", C.c_uint64 * 3),
-                ("site_wait_cycles", C.c_uint64 * 8)]
+                ("site_wait_cycles", C.c_uint64 * 8),
+                ("shade_iterations", C.c_uint64), ("shade_slots", C.c_uint64), ("shade_cycles", C.c_uint64)]
 
 
 class ValuProbe(C.Structure):
@@ -101,7 +102,7 @@ RT_ERR_INVALID, RT_ERR_HIP, RT_ERR_NO_SCENE, RT_ERR_LIMIT, RT_ERR_IO = -1, -2, -
 RT_OPT_PIPELINE, RT_OPT_PROBE_HITS, RT_OPT_COUNTERS, RT_OPT_PRESENT = 1, 2, 3, 4
 RT_OPT_FRAME_STRIDE, RT_OPT_SEED_MODE = 5, 6
 RT_OPT_TILE_ORDER, RT_OPT_VOTE_WEIGHTS, RT_OPT_BLOCKS_PER_CU = 7, 8, 9
-RT_OPT_FORCE_BIG_OFFSETS, RT_OPT_FAST_DIV, RT_OPT_TILE_DEAL = 10, 11, 12
+RT_OPT_FORCE_BIG_OFFSETS, RT_OPT_FAST_DIV, RT_OPT_TILE_DEAL, RT_OPT_POOL_SLOTS = 10, 11, 12, 13
 RT_MAT_GENERIC, RT_MAT_NORMAL, RT_MAT_EMISSIVE = 0, 1, 2
 RT_MAT_REFRACTIVE, RT_MAT_UV, RT_MAT_DIFFUSE, RT_MAT_METAL = 3, 4, 5, 6
 RT_DEBUG_NONE, RT_DEBUG_TRIANGLE_INTERSECTION, RT_DEBUG_BVH_INTERSECTION = 0, 1, 2

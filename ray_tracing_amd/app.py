@@ -180,7 +180,8 @@ class App:
         s = L.SchedStats()
         self._check(self._lib.rt_get_sched_stats(self._ctx, C.byref(s)))
         return {"iterations": list(s.iterations), "lanes": list(s.lanes), "cycles": list(s.cycles), "wait_cycles": list(s.wait_cycles),
-                "site_wait_cycles": list(s.site_wait_cycles)}
+                "site_wait_cycles": list(s.site_wait_cycles),
+                "shade": [int(s.shade_iterations), int(s.shade_slots), int(s.shade_cycles)]}
 
     def reset_stats(self):
         self._check(self._lib.rt_reset_stats(self._ctx))

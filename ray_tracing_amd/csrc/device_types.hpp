@@ -133,6 +133,8 @@ struct DevStats {
     unsigned long long iters[3], lanes[3], cycles[3], wait_cycles[3];
     // cycles waves spent waiting for memory (global, LDS, scalar) at marked places of the steps
     unsigned long long site_wait[8];
+    // the pooled kernel's SHADE steps: iterations, slots shaded, cycles
+    unsigned long long shade_iters, shade_lanes, shade_cycles;
 };
 
 // Work queues of the persistent kernel: 8 ranges of 64-pixel items (8x8 tiles),
@@ -150,6 +152,7 @@ struct DevQueue {
     const uint32_t* order;
     uint32_t* cost;
     uint32_t deal;  // how order_tiles_kernel shares the sorted tiles out: 1 dealt in turn, 0 a band per queue
+    uint32_t pool_slots;  // pooled kernel: ray slots a wave uses, 64..192 (0: all)
 };
 
 struct DevFrame {

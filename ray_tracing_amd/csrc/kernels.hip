@@ -332,63 +332,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((COUNT |
                 // index: the ray moves into the instance's object space, the root box is tested
                 // against the clamp (EPS, record.t) -- rec.t itself -- and the lane either enters
                 // the instance's tree or moves on to index u + 1 within the same pass.
-                bool looking = phase == ST_CONTROL && ctl == CT_NEXT_INSTANCE;
-                for (uint32_t u = 0; u < sc.n_instances; ++u) {
-                    const bool mine = looking && inst == u;
-                    if (__ballot(mine) == 0ull) continue;
-                    const ConstInstance I = inst_base + u;
-                    float m[12];
-#pragma unroll
-                    for (int k = 0; k < 12; ++k) m[k] = I->inv[k];
-                    const V3 np = xf_point(m, ray.pos), nd = xf_vector(m, ray.dir);
-                    const bool in_range = dir_rcp_ok(np, nd, sc.fast_div != 0u);
-                    const float blox = I->root.lox[0], bloy = I->root.loy[0], bloz = I->root.loz[0];
-                    const float bhix = I->root.hix[0], bhiy = I->root.hiy[0], bhiz = I->root.hiz[0];
-                    const uint32_t a = I->root.a[0], b = I->root.b[0];
-                    wait_site(1);
-                    const bool is_internal = b == kInternalTag, has_tris = a <= b;
-                    // First from the hardware's approximate reciprocals (three instructions): most
-                    // lanes miss most root boxes, clearly.  Only when some lane hits one, or cannot
-                    // tell, are the correctly rounded reciprocals formed -- the traversal needs them
-                    // then anyway.
-                    const SlabApprox sa = slab_approx(blox, bloy, bloz, bhix, bhiy, bhiz, np.x, np.y, np.z,
-                                                      __builtin_amdgcn_rcpf(nd.x), __builtin_amdgcn_rcpf(nd.y),
-                                                      __builtin_amdgcn_rcpf(nd.z));
-                    const float dist_apx = slab_dist(sa);
-                    const bool vague = slab_ambiguous(sa, rec.t, kSlabMarginApproxRcp);
-                    const bool amb = mine && (!in_range || vague);
-                    const bool may_enter = amb || (mine && dist_apx != RT_INF && !(dist_apx > rec.t));
-                    bool enter = false;
-                    if (__ballot(may_enter) != 0ull) {
-                        const DirRcp nr = make_dir_rcp(np, nd, sc.fast_div != 0u);
-                        float dist = dist_apx;
-                        if (__ballot(amb) != 0ull) {
-                            const float4 lo4 = make_float4(blox, bloy, bloz, 0.0f), hi4 = make_float4(bhix, bhiy, bhiz, 0.0f);
-                            const bool out_of_range = mine && !in_range;
-                            if (__ballot(out_of_range) == 0ull) dist = hits_bounding_rcp(np, nd, nr, lo4, hi4);
-                            else dist = hits_bounding(np, nd, lo4, hi4);
-                        }
-                        const bool hit_box = dist != RT_INF, within = !(dist > rec.t);
-                        enter = mine && hit_box && within && (is_internal || has_tris);
-                        const bool enter_node = enter && is_internal, enter_leaf = enter && !is_internal;
-                        dpx = enter ? f2{np.x, nd.x} : dpx;
-                        dpy = enter ? f2{np.y, nd.y} : dpy;
-                        dpz = enter ? f2{np.z, nd.z} : dpz;
-                        rcx = enter ? nr.x : rcx;
-                        rcy = enter ? nr.y : rcy;
-                        rcz = enter ? nr.z : rcz;
-                        rcp_ok = enter ? nr.ok : rcp_ok;
-                        cull = enter ? I->cull != 0u : cull;
-                        sp = enter ? 0u : sp;
-                        phase = enter_node ? (uint32_t)ST_DESC : enter_leaf ? (uint32_t)ST_LEAF : phase;
-                        cur = enter_node ? a << 1 : enter_leaf ? a : cur;
-                        tri_last = enter_leaf ? b : tri_last;
-                        next_off = enter_node ? node_item(a) : next_off;
-                    }
-                    if (COUNT) rec.box_tests += mine ? 1u : 0u;
-                    inst = (mine && !enter) ? u + 1u : inst;
-                    looking = looking && !enter;
-                }
+#include "instance_walk.inc"
                 if (looking) ctl = CT_SHADE;  // every instance has been visited
                 if (round == 1) break;  // whoever is through with its instances now is shaded in the next CONTROL step
                 // (2)
@@ -456,252 +400,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((COUNT |
                 if (__ballot(phase == ST_CONTROL && ctl == CT_NEXT_INSTANCE) == 0ull) break;
             }
         } else {
-            bool finished;  // this lane has to pop (or its instance is done)
-            const V3 lpos = v3(dpx.x, dpy.x, dpz.x), ldir = v3(dpx.y, dpy.y, dpz.y);
-            if (pick == 2) {
-                // `for i in first..=last`, hit.rs:111-121, for every lane that stands at a leaf --
-                // shared out over the whole wave.  The (lane, triangle) pairs of all those lanes
-                // ("owners") are numbered consecutively; worker lane w takes pair w: it borrows the
-                // owner's ray, fetches the triangle's DevTriTest and tests it (plane and lower range
-                // check as in triangle_ray_intersect, then the three edge signs from the approximate
-                // edge functions; unclear signs -> the exact test on the full triangle).  The upper
-                // range check, t > t_max, is the one part of the test that depends on the triangles
-                // before it, so it is left to the owner: each owner walks through its results in
-                // triangle order and keeps a candidate when it is not beyond the best so far --
-                // which lets a later triangle at the same distance win, as in hit.rs:115, and lets
-                // anything follow a NaN distance (a zero-area triangle), as the reference's
-                // comparisons do.  One pass covers 64 pairs; the rest stays for the next LEAF step.
-                const bool owner = phase == ST_LEAF;
-                const uint32_t c = owner ? tri_last - cur + 1u : 0u;
-                const uint32_t incl = wave_incl_sum(c), excl = incl - c;
-                const uint32_t room = excl < 64u ? 64u - excl : 0u;
-                const uint32_t n_proc = c < room ? c : room;
-                // worker w -> owner: owners mark the first of their pairs, a running maximum spreads the mark
-                // (a wave's LDS operations complete in program order; the empty asm statements keep the
-                // compiler from forwarding this lane's own store to its load, which must see other
-                // lanes' stores)
-                uint32_t* const tmp = &s_tmp[threadIdx.x & ~63u];
-                tmp[lane] = 0u;
-                asm volatile("" ::: "memory");
-                if (n_proc != 0u) tmp[excl] = lane + 1u;
-                asm volatile("" ::: "memory");
-                uint32_t tmp_mine = tmp[lane];
-                wait_site(4);
-                const uint32_t own1 = wave_incl_max(tmp_mine);
-                const uint32_t o = own1 != 0u ? own1 - 1u : lane;
-                // the owner's first pair, pair count and culling rule travel in one word
-                const uint32_t o_info = (uint32_t)__shfl((int)(excl | (n_proc << 8) | (cull ? 1u << 16 : 0u)), (int)o, 64);
-                const uint32_t kw = lane - (o_info & 0xFFu);
-                const bool has_owner = own1 != 0u, in_range = kw < ((o_info >> 8) & 0xFFu);
-                const bool work = has_owner && in_range;
-                const uint32_t tri = (uint32_t)__shfl((int)cur, (int)o, 64) + kw;
-                f4 b0 = {0.0f, 0.0f, 0.0f, 0.0f}, b1 = b0, b2 = b0, b3 = b0;
-                if (work) {
-                    const f4* p = tri_test_ptr(tri);
-                    b0 = p[0];
-                    b1 = p[1];
-                    b2 = p[2];
-                    b3 = p[3];
-                }
-                // the owner's ray, clamp and culling rule
-                const f2 wx = {__shfl(dpx.x, (int)o, 64), __shfl(dpx.y, (int)o, 64)};
-                const f2 wy = {__shfl(dpy.x, (int)o, 64), __shfl(dpy.y, (int)o, 64)};
-                const f2 wz = {__shfl(dpz.x, (int)o, 64), __shfl(dpz.y, (int)o, 64)};
-                const bool w_cull = (o_info & (1u << 16)) != 0u;
-                wait_site(5);
-                const V3 wpos = v3(wx.x, wy.x, wz.x), wdir = v3(wx.y, wy.y, wz.y);
-                // (n . pos, n . dir) in one go: dot's order, (x + y) + z, in both halves
-                const f2 np_nd = (splat(b0.x) * wx + splat(b0.y) * wy) + splat(b0.z) * wz;
-                const float dot_prod = np_nd.y;
-                const bool grazing = fabsf(dot_prod) < kEps, back = dot_prod > 0.0f;
-                float t = -(np_nd.x + b0.w) / dot_prod;
-                const bool before = t < kEps;
-                const bool back_culled = w_cull && back;
-                const bool out = grazing || back_culled || before;
-                const V3 g = (wpos + wdir * t) - v3(b1.x, b1.y, b1.z);
-                const f2 s01 = (b2.xy * splat(g.x) + b2.zw * splat(g.y)) + b3.xy * splat(g.z);
-                const TriSigns sg = tri_filter_signs(s01.x, s01.y, b1.w, b3.z, b3.w, g.x, g.y, g.z);
-                const bool vague = tri_filter_unclear(sg), outside = sg.s_min < 0.0f;
-                const bool unclear = work && !out && vague;
-                const bool miss = !work || out || outside;
-                t = miss ? RT_INF : t;
-                if (__ballot(unclear) != 0ull) {
-                    if (unclear) {
-                        const float4* fp = reinterpret_cast<const float4*>(&sc.tris[tri]);
-                        t = triangle_ray_intersect(fp[0], fp[1], fp[2], fp[3].x, wpos, wdir, kEps, RT_INF, w_cull);
-                    }
-                    wait_site(6);
-                }
-                // What an owner keeps of its results is what the sequential loop would keep: a
-                // candidate (a finite distance) is accepted when it is not beyond the best so far,
-                // so the survivor is the smallest candidate that is not beyond the clamp, the last
-                // one among equals.  With no NaN among the results that is a minimum over
-                // (distance, position from the end): the workers fold their candidates into the
-                // owner's LDS slot with one 64-bit atomic minimum each (distances are >= EPS > 0,
-                // so their bit patterns order like the numbers).  A NaN clamp accepts everything,
-                // as `t > NaN` is false.  A NaN result (a zero-area triangle) makes what follows
-                // it depend on the order, so such a wave walks through the results one by one.
-                float best = rec.t;
-                uint32_t best_k = 0xFFFFFFFFu;
-                const bool t_nan = t != t;
-                if (__ballot(t_nan) == 0ull) {
-                    const float o_clamp = __shfl(rec.t, (int)o, 64);
-                    unsigned long long* const slot = &s_best[threadIdx.x & ~63u];
-                    slot[lane] = ~0ull;
-                    asm volatile("" ::: "memory");
-                    const bool cand = work && !is_inf_bits(t) && !(t > o_clamp);
-                    if (cand) atomicMin(&slot[o], ((unsigned long long)__float_as_uint(t) << 32) | (0xFFFFFFFFu - kw));
-                    asm volatile("" ::: "memory");
-                    const unsigned long long kept = slot[lane];
-                    wait_site(7);
-                    const bool any = owner && kept != ~0ull;
-                    best = any ? __uint_as_float((uint32_t)(kept >> 32)) : best;
-                    best_k = any ? 0xFFFFFFFFu - (uint32_t)kept : best_k;
-                } else {
-                    for (uint32_t k0 = 0; __ballot(k0 < n_proc) != 0ull; k0 += 4u) {
-                        float tk[4];  // four results on their way at a time
-#pragma unroll
-                        for (uint32_t j = 0; j < 4u; ++j) tk[j] = __shfl(t, (int)((excl + k0 + j) & 63u), 64);
-#pragma unroll
-                        for (uint32_t j = 0; j < 4u; ++j) {
-                            const bool mine = k0 + j < n_proc, finite = !is_inf_bits(tk[j]), farther = tk[j] > best;
-                            const bool keep = mine && finite && !farther;
-                            best = keep ? tk[j] : best;
-                            best_k = keep ? k0 + j : best_k;
-                        }
-                    }
-                }
-                const bool hit = best_k != 0xFFFFFFFFu;
-                rec.t = hit ? best : rec.t;
-                rec.triangle_id = hit ? cur + best_k : rec.triangle_id;
-                rec.instance_id = hit ? inst : rec.instance_id;
-                if (COUNT) rec.triangle_tests += n_proc;
-                cur += n_proc;
-                finished = owner && cur == tri_last + 1u;
-            } else {
-                // The item is an internal node; both child boxes are tested at once.
-                //   ST_DESC: the node passed its own test (hit.rs:88-107).  The children are
-                //     ordered by centre distance; the nearer one is the node the reference pops
-                //     next.  The farther one it would test when popping it later: a ray that
-                //     misses that box altogether misses it whenever it is popped, so that outcome
-                //     is taken now and the entry is never pushed; a box that IS hit still waits on
-                //     the stack and is tested again at pop time against the clamp of that moment.
-                //   ST_POP: only child `cur & 1` is looked at: the node on top of the reference's
-                //     stack (hit.rs:77-86).
-                const bool desc = phase == ST_DESC;
-                const bool popping = phase == ST_POP;
-                const bool act = desc || popping;
-                const float lox[2] = {it0.x, it0.y}, hix[2] = {it0.z, it0.w};
-                const float loy[2] = {it1.x, it1.y}, hiy[2] = {it1.z, it1.w};
-                const float loz[2] = {it2.x, it2.y}, hiz[2] = {it2.z, it2.w};
-                const uint32_t a0 = __float_as_uint(it3.x), a1 = __float_as_uint(it3.y);
-                const uint32_t b0 = __float_as_uint(it3.z), b1 = __float_as_uint(it3.w);
-                const float px = dpx.x, py = dpy.x, pz = dpz.x;
-                // BoundingBox::center (shared/src/lib.rs:155-157) and hit.rs:92-100
-                float d2c[2];
-#pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    const float ex = (lox[k] + hix[k]) * 0.5f - px, ey = (loy[k] + hiy[k]) * 0.5f - py,
-                                ez = (loz[k] + hiz[k]) * 0.5f - pz;
-                    d2c[k] = (ex * ex + ey * ey) + ez * ez;
-                }
-                const bool first_is_1 = d2c[0] < d2c[1];
-                // the child tested "now" is child 0.  Every condition of this step is computed into a
-                // named flag first and the flags are then combined: the step is meant to be one
-                // straight run of instructions, not a tree of branches.
-                const bool slot0 = (cur & 1u) == 0u;
-                const bool by_order = desc && first_is_1, by_slot = !desc && slot0;
-                const bool near0 = by_order || by_slot;
-                if (COUNT) {
-                    // a popped child was counted when its parent was visited
-                    rec.internal_visits += desc ? 1u : 0u;
-                    rec.box_tests += desc ? 2u : 0u;
-                }
-                // Three ways to the same decisions, chosen per wave.  The plain division is right
-                // for every lane; quotients through the cached reciprocal need the lane's operands
-                // in range; approximate quotients also need every comparison to be clear-cut.
-                // One lane outside a premise moves the whole wave to the next, dearer form.
-                // The approximate form picks each slab's entry and exit plane by the sign of the
-                // reciprocal (a bitwise select) instead of ordering the two quotients: the same values
-                // whenever min <= max and the reciprocal is finite, which the premises include.
-                const uint32_t mx = (uint32_t)((int32_t)__float_as_uint(rcx) >> 31),
-                               my = (uint32_t)((int32_t)__float_as_uint(rcy) >> 31),
-                               mz = (uint32_t)((int32_t)__float_as_uint(rcz) >> 31);
-                auto pick = [](uint32_t m, float when_set, float when_clear) {
-                    return __uint_as_float((__float_as_uint(when_set) & m) | (__float_as_uint(when_clear) & ~m));
-                };
-                float tn_[2], tf_[2];
-#pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    const float nx = (pick(mx, hix[k], lox[k]) - px) * rcx, fx = (pick(mx, lox[k], hix[k]) - px) * rcx;
-                    const float ny = (pick(my, hiy[k], loy[k]) - py) * rcy, fy = (pick(my, loy[k], hiy[k]) - py) * rcy;
-                    const float nz = (pick(mz, hiz[k], loz[k]) - pz) * rcz, fz = (pick(mz, loz[k], hiz[k]) - pz) * rcz;
-                    tn_[k] = __builtin_fmaxf(__builtin_fmaxf(nx, ny), nz);
-                    tf_[k] = __builtin_fminf(__builtin_fminf(fx, fy), fz);
-                }
-                const f2 tn = {tn_[0], tn_[1]}, tf = {tf_[0], tf_[1]};
-                const SlabApprox s0 = {tn.x, tf.x}, s1 = {tn.y, tf.y};
-                const bool amb0 = slab_ambiguous(s0, rec.t), amb1 = slab_ambiguous(s1, rec.t);
-                // a descent needs both children clear-cut, a pop only the child it looks at
-                const bool look0 = desc || near0, look1 = desc || !near0;
-                const bool unclear0 = amb0 && look0, unclear1 = amb1 && look1;
-                const bool amb = act && (!rcp_ok || unclear0 || unclear1);
-                float dist0 = slab_dist(s0), dist1 = slab_dist(s1);
-                if (__ballot(amb) != 0ull) {
-                    const bool out_of_range = act && !rcp_ok;
-                    const bool all_fast = __ballot(out_of_range) == 0ull;
-                    const float4 lo0 = make_float4(lox[0], loy[0], loz[0], 0.0f), hi0 = make_float4(hix[0], hiy[0], hiz[0], 0.0f);
-                    const float4 lo1 = make_float4(lox[1], loy[1], loz[1], 0.0f), hi1 = make_float4(hix[1], hiy[1], hiz[1], 0.0f);
-                    if (all_fast) {
-                        DirRcp r;
-                        r.x = rcx;
-                        r.y = rcy;
-                        r.z = rcz;
-                        r.ok = true;
-                        dist0 = hits_bounding_rcp(lpos, ldir, r, lo0, hi0);
-                        dist1 = hits_bounding_rcp(lpos, ldir, r, lo1, hi1);
-                    } else {
-                        dist0 = hits_bounding(lpos, ldir, lo0, hi0);
-                        dist1 = hits_bounding(lpos, ldir, lo1, hi1);
-                    }
-                }
-                const float near_dist = near0 ? dist0 : dist1, far_dist = near0 ? dist1 : dist0;
-                const bool far_hit = far_dist != RT_INF, far_within = !(far_dist > rec.t);
-                const bool near_hit = near_dist != RT_INF, near_within = !(near_dist > rec.t);
-                const bool far_alive = desc && far_hit;
-                const bool near_alive = near_hit && near_within;
-                const bool push = near_alive && far_alive;
-                // the nearer child is out: the reference pops the farther one next, clamp unchanged
-                const bool take_far = !near_alive && far_alive;
-                const bool far_taken = take_far && far_within;
-                const bool alive = near_alive || far_taken;
-                if (push) stack[sp * kBlock] = (cur & ~1u) | (near0 ? 1u : 0u);  // the farther child's slot
-                sp += push ? 1u : 0u;
-                const bool chosen0 = near0 != take_far;
-                const uint32_t a = chosen0 ? a0 : a1, b = chosen0 ? b0 : b1;
-                const bool is_internal = b == kInternalTag, has_tris = a <= b;  // a > b: `first..=last` with nothing in it
-                const bool go = act && alive;
-                const bool internal = go && is_internal;
-                const bool leaf = go && !is_internal && has_tris;
-                finished = act && !internal && !leaf;
-                phase = internal ? (uint32_t)ST_DESC : leaf ? (uint32_t)ST_LEAF : phase;
-                cur = internal ? a << 1 : leaf ? a : cur;
-                tri_last = leaf ? b : tri_last;
-                next_off = internal ? node_item(a) : next_off;  // a leaf's triangles are fetched by the LEAF step
-            }
-            // a lane that is through with its node or leaf: pop, or this instance is done (trace.rs:76)
-            const bool empty = sp == 0u;
-            const bool pop = finished && !empty;
-            const bool inst_end = finished && empty;
-            uint32_t ref = 0;
-            if (pop) ref = stack[(sp - 1u) * kBlock];
-            wait_site(3);
-            sp -= pop ? 1u : 0u;
-            inst += inst_end ? 1u : 0u;
-            phase = pop ? (uint32_t)ST_POP : inst_end ? (uint32_t)ST_CONTROL : phase;
-            cur = pop ? ref : cur;
-            ctl = inst_end ? (uint32_t)CT_NEXT_INSTANCE : ctl;  // on to the next instance, if there is one
-            next_off = pop ? node_item(ref >> 1) : next_off;
+#include "traverse_steps.inc"
         }
         if (next_off != kNoItem) {
             const f4* p = item_ptr(next_off);
@@ -720,6 +419,370 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((COUNT |
             atomicAdd(&fr.stats->cycles[k], sched_cycles[k]);
             atomicAdd(&fr.stats->wait_cycles[k], sched_wait[k]);
         }
+        for (int k = 0; k < 8; ++k) atomicAdd(&fr.stats->site_wait[k], site_wait[k]);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Pooled persistent kernel.
+//
+// The same steps on the same per-ray arithmetic as path_kernel_persistent, with one change of
+// ownership: a lane no longer keeps one pixel from its first frame to its last.  Every wave owns
+// a pool of 192 ray slots (three per lane), each a 128-byte record in global memory that holds a
+// pixel's bookkeeping (position, accumulator, frames left) and its current path (seed, segment
+// number, throughput, ray, and the hit record of the segment just traced).  Lanes only
+// TRAVERSE: a lane takes a slot whose next segment is ready, loads the ray, walks the instances
+// and their trees (CONTROL, BOX and LEAF steps as before), writes the hit record back and takes
+// the next ready slot.  Everything else a path needs -- shading, accumulation, the next frame's
+// seed and camera ray, the next pixel from the work queues -- happens in SHADE steps, which the
+// wave runs when 64 slots are waiting for one: every lane then shades a slot, whichever lane
+// traced it.  Two things follow.  Shading, the longest piece of straight code in the kernel,
+// runs with all 64 lanes instead of the 24 a CONTROL step used to gather; and a lane that
+// finishes a segment does not wait for its neighbours to finish theirs, it goes on with
+// another ray, so the BOX and LEAF steps find more lanes that want them.
+//
+// The pool is private to the wave (no other wave reads or writes its slots or its slot states),
+// so all bookkeeping is wave-synchronous: ballots, prefix counts and a few LDS words, no atomics
+// and no waiting on other waves.  Which lane traces which pixel changes no pixel's value.
+// ---------------------------------------------------------------------------
+constexpr uint32_t kSlotsPerLane = 3u;
+constexpr uint32_t kWaveSlots = 64u * kSlotsPerLane;
+enum : uint32_t { SL_NEW = 0, SL_READY = 1, SL_TRAVERSING = 2, SL_PENDING = 3, SL_RETIRED = 4 };
+enum : uint32_t { CT_IDLE = 5, CT_DONE = 6, CT_READY = 7, CT_RETIRE = 8 };
+
+// line 0: ray origin, seed | 1: ray direction, segment number | 2: throughput, pixel (x | y << 16)
+// | 3: accumulator | 4: hit record of the traced segment (t, triangle, instance, box tests)
+// | 5: frames_without_move, frame, tile, frames left | 6: internal visits, triangle tests | 7: --
+struct alignas(128) RayRecord {
+    f4 line[8];
+};
+static_assert(sizeof(RayRecord) == 128, "one record is 128 bytes");
+
+template <int STACK_N, bool COUNT, bool BIG>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((COUNT || STACK_N > 32) ? 1 : 4))) void path_kernel_pool(
+    DevScene sc, DevCam cam, DevRows rows, DevFrame fr, DevQueue q, uint32_t n_frames, RayRecord* records) {
+    __shared__ uint32_t s_stack[STACK_N * kBlock];
+    __shared__ uint32_t s_tmp[kBlock];  // 64 words per wave: who works for whom in a LEAF step; slots dealt to lanes
+    __shared__ unsigned long long s_best[kBlock];  // per lane: what an owner keeps of a LEAF step's results
+    __shared__ uint32_t s_state[kBlock * kSlotsPerLane];  // per wave: the states of its 192 slots
+
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t* const stack = &s_stack[threadIdx.x];
+    const unsigned long long lanes_below = (1ull << lane) - 1ull;
+    uint32_t* const state = &s_state[wave * kWaveSlots];
+    uint32_t* const deal = &s_tmp[threadIdx.x & ~63u];
+    RayRecord* const pool = records + (size_t)(blockIdx.x * (kBlock / 64u) + wave) * kWaveSlots;
+
+    unsigned long long n_rays = 0, n_box = 0, n_internal = 0, n_tri = 0, n_paths = 0;
+    unsigned long long sched_iters[4] = {0, 0, 0, 0}, sched_lanes[4] = {0, 0, 0, 0}, sched_cycles[4] = {0, 0, 0, 0},
+                       sched_wait[4] = {0, 0, 0, 0};  // wave-uniform
+    unsigned long long site_wait[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // wave-uniform, profile only
+    auto wait_site = [&](int site) {
+        if (COUNT) {
+            const unsigned long long t0 = __builtin_readcyclecounter();
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            site_wait[site] += __builtin_readcyclecounter() - t0;
+        }
+    };
+    auto node_item = [&](uint32_t a) -> uint32_t { return BIG ? sc.node_unit + a : sc.node_off + a * 64u; };
+    auto item_ptr = [&](uint32_t item) -> const f4* {
+        return reinterpret_cast<const f4*>(BIG ? sc.arena + ((unsigned long long)item << 6) : sc.arena + item);
+    };
+    auto tri_test_ptr = [&](uint32_t tri) -> const f4* {
+        return reinterpret_cast<const f4*>(BIG ? sc.arena + ((unsigned long long)(sc.tri_test_unit + tri) << 6)
+                                               : sc.arena + (sc.tri_test_off + tri * 64u));
+    };
+    const ConstInstance inst_base = (ConstInstance)(uintptr_t)sc.instances;
+
+    // the wave's slots: all waiting for a pixel
+    const uint32_t slots_in_use = q.pool_slots >= 64u && q.pool_slots <= kWaveSlots ? q.pool_slots : kWaveSlots;
+    state[lane] = SL_NEW;
+    state[lane + 64u] = lane + 64u < slots_in_use ? (uint32_t)SL_NEW : (uint32_t)SL_RETIRED;
+    state[lane + 128u] = lane + 128u < slots_in_use ? (uint32_t)SL_NEW : (uint32_t)SL_RETIRED;
+    asm volatile("" ::: "memory");
+    // wave-uniform census of the slot states (kept in step with every change below)
+    uint32_t n_new = n_frames > 0 ? slots_in_use : 0u, n_ready = 0, n_pending = 0, n_live = n_new;
+    uint32_t queues_tried = 0;  // wave-uniform: how many queues this wave has found empty
+    uint32_t stalls = 0;        // wave-uniform: iterations that found nothing to do (cannot happen; bounds the loop)
+
+    // the lane as a traverser
+    uint32_t phase = ST_CONTROL, ctl = CT_IDLE;
+    uint32_t slot = 0, inst = 0;
+    Ray ray;
+    ray.pos = v3(0.0f, 0.0f, 0.0f);
+    ray.dir = v3(0.0f, 0.0f, 1.0f);
+    HitRecord rec;  // rec.t doubles as the traversal's clamp: trace.rs:89 hands it to hit_bvh as t_max
+    record_new(rec);
+    f2 dpx = {0.0f, 0.0f}, dpy = {0.0f, 0.0f}, dpz = {0.0f, 1.0f};
+    float rcx = 1.0f, rcy = 1.0f, rcz = 1.0f;
+    bool rcp_ok = false;
+    bool cull = false;
+    f4 it0 = {0.0f, 0.0f, 0.0f, 0.0f}, it1 = it0, it2 = it0, it3 = it0;  // the pending item
+    uint32_t cur = 0;  // ST_DESC / ST_POP: (node index << 1) | child slot;  ST_LEAF: triangle index
+    uint32_t tri_last = 0, sp = 0;
+
+    while (n_live != 0u) {
+        uint32_t next_off = kNoItem;
+        const unsigned long long t_begin = COUNT ? __builtin_readcyclecounter() : 0ull;
+        // wave-uniform choice of the one kind of step this iteration runs
+        const uint32_t n_ctl = (uint32_t)__popcll(__ballot(phase == ST_CONTROL && ctl != CT_IDLE));
+        const uint32_t n_idle = (uint32_t)__popcll(__ballot(phase == ST_CONTROL && ctl == CT_IDLE));
+        const uint32_t n_claim = n_idle < n_ready ? n_idle : n_ready;
+        const int w_ctl = (int)(n_ctl + n_claim) * q.w_ctl;
+        const int w_box = __popcll(__ballot(phase == ST_DESC || phase == ST_POP)) * q.w_box;
+        const int w_leaf = __popcll(__ballot(phase == ST_LEAF)) * q.w_leaf;
+        const uint32_t n_shadeable = n_pending + n_new;
+        int pick = 1, w_best = w_box;
+        if (w_leaf > w_best) pick = 2, w_best = w_leaf;
+        if (w_ctl > w_best) pick = 0, w_best = w_ctl;
+        // a full batch is shaded at once; a partial one when lanes are out of rays to trace
+        if (n_shadeable >= 64u || (n_shadeable != 0u && (w_best == 0 || (n_ready == 0u && n_idle >= 16u)))) pick = 3;
+        else if (w_best == 0) {
+            if (++stalls > 1000u) break;
+            continue;
+        }
+        if (COUNT) {
+            const unsigned long long t0 = __builtin_readcyclecounter();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            sched_wait[pick] += __builtin_readcyclecounter() - t0;
+            sched_iters[pick] += 1;
+            sched_lanes[pick] += (unsigned)(pick == 0 ? w_ctl / q.w_ctl : pick == 1 ? w_box / q.w_box
+                                            : pick == 2 ? w_leaf / q.w_leaf : (n_shadeable < 64u ? n_shadeable : 64u));
+        }
+
+        if (pick == 3) {
+            // ---- SHADE: up to 64 slots that wait for a pixel or for the rest of trace_ray ----
+            asm volatile("" ::: "memory");
+            const uint32_t st0 = state[lane], st1 = state[lane + 64u], st2 = state[lane + 128u];
+            const bool f0 = st0 == SL_PENDING || st0 == SL_NEW, f1 = st1 == SL_PENDING || st1 == SL_NEW,
+                       f2_ = st2 == SL_PENDING || st2 == SL_NEW;
+            const unsigned long long m0 = __ballot(f0), m1 = __ballot(f1), m2 = __ballot(f2_);
+            const uint32_t c0 = (uint32_t)__popcll(m0), c1 = (uint32_t)__popcll(m1);
+            const uint32_t r0 = (uint32_t)__popcll(m0 & lanes_below), r1 = c0 + (uint32_t)__popcll(m1 & lanes_below),
+                           r2 = c0 + c1 + (uint32_t)__popcll(m2 & lanes_below);
+            const uint32_t n_have = c0 + c1 + (uint32_t)__popcll(m2), n_take = n_have < 64u ? n_have : 64u;
+            if (f0 && r0 < 64u) deal[r0] = lane | (st0 == SL_NEW ? 0x80000000u : 0u);
+            if (f1 && r1 < 64u) deal[r1] = (lane + 64u) | (st1 == SL_NEW ? 0x80000000u : 0u);
+            if (f2_ && r2 < 64u) deal[r2] = (lane + 128u) | (st2 == SL_NEW ? 0x80000000u : 0u);
+            asm volatile("" ::: "memory");
+            const bool active = lane < n_take;
+            const uint32_t dealt = deal[lane];
+            const uint32_t my = dealt & 0xFFFFu;
+            const bool fresh = (dealt >> 31) != 0u;
+            f4* const r = pool[active ? my : 0u].line;
+            uint32_t sctl = active ? (fresh ? (uint32_t)CT_NEW_PIXEL : (uint32_t)CT_SHADE) : (uint32_t)CT_IDLE;
+            n_pending -= (uint32_t)__popcll(__ballot(active && !fresh));
+            n_new -= (uint32_t)__popcll(__ballot(active && fresh));
+            // the slot's pixel and path
+            uint32_t x = 0, y = 0, tile = 0, frame = 0, frames_left = 0, seed = 0, seg = 0;
+            float fwm = 0.0f;
+            float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            V3 color = v3(1.0f, 1.0f, 1.0f);
+            Ray pray;
+            pray.pos = v3(0.0f, 0.0f, 0.0f);
+            pray.dir = v3(0.0f, 0.0f, 1.0f);
+            HitRecord prec;
+            record_new(prec);
+            if (sctl == CT_SHADE) {
+                const f4 l0 = r[0], l1 = r[1], l2 = r[2], l3 = r[3], l4 = r[4], l5 = r[5];
+                pray.pos = v3(l0.x, l0.y, l0.z);
+                seed = __float_as_uint(l0.w);
+                pray.dir = v3(l1.x, l1.y, l1.z);
+                seg = __float_as_uint(l1.w);
+                color = v3(l2.x, l2.y, l2.z);
+                x = __float_as_uint(l2.w) & 0xFFFFu;
+                y = __float_as_uint(l2.w) >> 16;
+                acc = make_float4(l3.x, l3.y, l3.z, l3.w);
+                prec.t = l4.x;
+                prec.triangle_id = __float_as_uint(l4.y);
+                prec.instance_id = __float_as_uint(l4.z);
+                prec.box_tests = __float_as_uint(l4.w);
+                fwm = l5.x;
+                frame = __float_as_uint(l5.y);
+                tile = __float_as_uint(l5.z);
+                frames_left = __float_as_uint(l5.w);
+                if (COUNT) {
+                    const f4 l6 = r[6];
+                    prec.internal_visits = __float_as_uint(l6.x);
+                    prec.triangle_tests = __float_as_uint(l6.y);
+                }
+                // the rest of trace_ray, trace.rs:97-172
+                const uint32_t idx = x + y * cam.W;
+                if (seg == 0 && fr.hit_triangle) {
+                    fr.hit_triangle[idx] = prec.triangle_id;
+                    fr.hit_instance[idx] = prec.instance_id;
+                    fr.hit_t_bits[idx] = __float_as_uint(prec.t);
+                }
+                if (COUNT) {
+                    if (seg == 0 && fr.box_tests) {
+                        fr.box_tests[idx] = prec.box_tests;
+                        fr.triangle_tests[idx] = prec.triangle_tests;
+                    }
+                    n_box += prec.box_tests;
+                    n_internal += prec.internal_visits;
+                    n_tri += prec.triangle_tests;
+                }
+                int st = shade(sc, cam, prec, pray, seed, color);
+                seg += 1;
+                if (st == STATE_RAY && seg < cam.depth) {
+                    sctl = CT_START_SEGMENT;
+                } else {
+                    if (st == STATE_RAY) color = v3(0.0f, 0.0f, 0.0f);  // never finished bouncing, trace.rs:204-205
+                    // shader/src/lib.rs:71-98, then the event loop's bookkeeping, main.rs:147-148
+                    acc = accumulate_only(fwm, acc, color);
+                    n_paths += 1;
+                    frame += cam.frame_stride;
+                    fwm += 1.0f;
+                    frames_left -= 1u;
+                    sctl = CT_NEW_PATH;
+                    if (frames_left == 0u) {
+                        reinterpret_cast<float4*>(fr.acc)[idx] = acc;
+                        if (q.cost) atomicAdd(&q.cost[tile], seg);  // length of the pixel's last path
+                        sctl = CT_NEW_PIXEL;
+                    }
+                }
+            }
+            {
+                // one queue per XCD group; every lane that needs a pixel takes part in one fetch
+                const bool want = sctl == CT_NEW_PIXEL;
+                const unsigned long long wm = __ballot(want);
+                if (wm != 0ull) {
+                    const uint32_t n_want = (uint32_t)__popcll(wm);
+                    const uint32_t qi = ((blockIdx.x & 7u) + queues_tried) & 7u;
+                    const uint32_t q_first = q.first_item[qi], q_size = q.first_item[qi + 1] - q_first;
+                    uint32_t base = 0;
+                    if (lane == (uint32_t)__ffsll((long long)wm) - 1u) base = atomicAdd(&q.head[qi * 32u], n_want);
+                    base = __shfl(base, __ffsll((long long)wm) - 1, 64);
+                    if (base + n_want >= q_size) queues_tried += 1u;  // this queue is (about to be) empty
+                    if (want) {
+                        const uint32_t k = base + (uint32_t)__popcll(wm & lanes_below);
+                        if (k < q_size) {
+                            const uint32_t item = q_first + k;
+                            const uint32_t l = item & (kPT * kPT - 1u);
+                            tile = q.order ? q.order[item >> kPTShift] : item >> kPTShift;
+                            const uint32_t tile_y = tile / q.tiles_x, tile_x = tile - tile_y * q.tiles_x;
+                            x = tile_x * kPT + (l & (kPT - 1u));
+                            const uint32_t ly = tile_y * kPT + l / kPT;
+                            y = global_row(rows, ly);
+                            if (x < cam.W && ly < rows.local_rows && y < cam.H) {
+                                acc = reinterpret_cast<const float4*>(fr.acc)[x + y * cam.W];
+                                frame = cam.frame;
+                                fwm = cam.frames_without_move;
+                                frames_left = n_frames;
+                                sctl = CT_NEW_PATH;
+                            }
+                        } else if (queues_tried >= 8u) {
+                            sctl = CT_RETIRE;
+                        }
+                    }
+                }
+            }
+            if (sctl == CT_NEW_PATH) {
+                // shader/src/lib.rs:57-69 and Ray::get_color, trace.rs:175-191
+                seed = cam.seed_mode ? get_seed(frame, x, y, 0.0f, 0.0f, 0.0f) : get_seed(frame, x, y, acc.x, acc.y, acc.z);
+                color = v3(1.0f, 1.0f, 1.0f);
+                float jx = rand_float(seed, 0.0f, 1.0f);
+                float jy = rand_float(seed, 0.0f, 1.0f);
+                pray = camera_ray(cam, (float)x + jx, (float)y + jy);
+                pray.dir = normalize(pray.dir);
+                seg = 0;
+                sctl = CT_START_SEGMENT;
+            }
+            if (sctl == CT_START_SEGMENT) {
+                // head of Ray::trace_ray, trace.rs:73-74; the traversing lane does the rest
+                pray.dir = normalize(pray.dir);
+                n_rays += 1;
+                r[0] = f4{pray.pos.x, pray.pos.y, pray.pos.z, __uint_as_float(seed)};
+                r[1] = f4{pray.dir.x, pray.dir.y, pray.dir.z, __uint_as_float(seg)};
+                r[2] = f4{color.x, color.y, color.z, __uint_as_float(x | (y << 16))};
+                r[3] = f4{acc.x, acc.y, acc.z, acc.w};
+                r[5] = f4{fwm, __uint_as_float(frame), __uint_as_float(tile), __uint_as_float(frames_left)};
+                sctl = CT_READY;
+            }
+            if (active) state[my] = sctl == CT_READY ? (uint32_t)SL_READY : sctl == CT_RETIRE ? (uint32_t)SL_RETIRED : (uint32_t)SL_NEW;
+            asm volatile("" ::: "memory");
+            n_ready += (uint32_t)__popcll(__ballot(sctl == CT_READY));
+            n_new += (uint32_t)__popcll(__ballot(sctl == CT_NEW_PIXEL));
+            n_live -= (uint32_t)__popcll(__ballot(sctl == CT_RETIRE));
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the records are read again by this wave only, after this
+        } else if (pick == 0) {
+            // Two rounds of: (1) the instance loop of trace_ray (trace.rs:76-94) for every lane that
+            // stands between two instances, (2) hand the finished segments over, take ready ones.
+            for (int round = 0; round < 2; ++round) {
+#include "instance_walk.inc"
+                if (looking) ctl = CT_DONE;  // every instance has been visited
+                if (round == 1) break;
+                // (2a) segments whose instances are exhausted: the hit record goes to the slot
+                const bool done = phase == ST_CONTROL && ctl == CT_DONE;
+                const unsigned long long dm = __ballot(done);
+                if (dm != 0ull) {
+                    if (done) {
+                        f4* const r = pool[slot].line;
+                        r[4] = f4{rec.t, __uint_as_float(rec.triangle_id), __uint_as_float(rec.instance_id),
+                                  __uint_as_float(rec.box_tests)};
+                        if (COUNT) r[6] = f4{__uint_as_float(rec.internal_visits), __uint_as_float(rec.triangle_tests), 0.0f, 0.0f};
+                        state[slot] = SL_PENDING;
+                        ctl = CT_IDLE;
+                    }
+                    n_pending += (uint32_t)__popcll(dm);
+                    asm volatile("" ::: "memory");
+                }
+                // (2b) lanes without a ray take ready slots, in slot order
+                const bool idle = phase == ST_CONTROL && ctl == CT_IDLE;
+                const unsigned long long im = __ballot(idle);
+                const uint32_t n_free = (uint32_t)__popcll(im), n_take = n_free < n_ready ? n_free : n_ready;
+                if (n_take != 0u) {
+                    asm volatile("" ::: "memory");
+                    const uint32_t st0 = state[lane], st1 = state[lane + 64u], st2 = state[lane + 128u];
+                    const bool f0 = st0 == SL_READY, f1 = st1 == SL_READY, f2_ = st2 == SL_READY;
+                    const unsigned long long m0 = __ballot(f0), m1 = __ballot(f1), m2 = __ballot(f2_);
+                    const uint32_t c0 = (uint32_t)__popcll(m0), c1 = (uint32_t)__popcll(m1);
+                    const uint32_t r0 = (uint32_t)__popcll(m0 & lanes_below), r1 = c0 + (uint32_t)__popcll(m1 & lanes_below),
+                                   r2 = c0 + c1 + (uint32_t)__popcll(m2 & lanes_below);
+                    if (f0 && r0 < n_take) deal[r0] = lane;
+                    if (f1 && r1 < n_take) deal[r1] = lane + 64u;
+                    if (f2_ && r2 < n_take) deal[r2] = lane + 128u;
+                    asm volatile("" ::: "memory");
+                    const uint32_t k = (uint32_t)__popcll(im & lanes_below);
+                    if (idle && k < n_take) {
+                        slot = deal[k];
+                        state[slot] = SL_TRAVERSING;
+                        const f4* const r = pool[slot].line;
+                        const f4 l0 = r[0], l1 = r[1];
+                        ray.pos = v3(l0.x, l0.y, l0.z);
+                        ray.dir = v3(l1.x, l1.y, l1.z);
+                        record_new(rec);
+                        inst = 0;
+                        ctl = CT_NEXT_INSTANCE;
+                    }
+                    asm volatile("" ::: "memory");
+                    n_ready -= n_take;
+                }
+                if (__ballot(phase == ST_CONTROL && ctl == CT_NEXT_INSTANCE) == 0ull) break;
+            }
+        } else {
+#include "traverse_steps.inc"
+        }
+        if (next_off != kNoItem) {
+            const f4* p = item_ptr(next_off);
+            it0 = p[0];
+            it1 = p[1];
+            it2 = p[2];
+            it3 = p[3];
+        }
+        if (COUNT) sched_cycles[pick] += __builtin_readcyclecounter() - t_begin;
+    }
+    flush_stats(fr, COUNT, lane, n_rays, n_paths, n_box, n_internal, n_tri);
+    if (COUNT && lane == 0 && fr.stats) {
+        for (int k = 0; k < 3; ++k) {
+            atomicAdd(&fr.stats->iters[k], sched_iters[k]);
+            atomicAdd(&fr.stats->lanes[k], sched_lanes[k]);
+            atomicAdd(&fr.stats->cycles[k], sched_cycles[k]);
+            atomicAdd(&fr.stats->wait_cycles[k], sched_wait[k]);
+        }
+        atomicAdd(&fr.stats->shade_iters, sched_iters[3]);
+        atomicAdd(&fr.stats->shade_lanes, sched_lanes[3]);
+        atomicAdd(&fr.stats->shade_cycles, sched_cycles[3]);
         for (int k = 0; k < 8; ++k) atomicAdd(&fr.stats->site_wait[k], site_wait[k]);
     }
 }
@@ -795,7 +858,7 @@ hipError_t launch_path_kernel(const DevScene& sc, const DevCam& cam, const DevRo
 
 hipError_t launch_persistent_kernel(const DevScene& sc, const DevCam& cam, const DevRows& rows, const DevFrame& fr,
                                     DevQueue q, uint32_t* order_out, uint32_t n_frames, uint32_t stack_needed,
-                                    bool count, bool big, uint32_t n_blocks, hipStream_t stream) {
+                                    bool count, bool big, uint32_t n_blocks, void* pool_records, hipStream_t stream) {
     // 8x8-pixel tiles of this context's rows, split into 8 contiguous ranges
     q.tiles_x = (cam.W + kPT - 1u) / kPT;
     const uint32_t tiles_y = (rows.local_rows + kPT - 1u) / kPT;
@@ -808,8 +871,15 @@ hipError_t launch_persistent_kernel(const DevScene& sc, const DevCam& cam, const
     if (e != hipSuccess) return e;
     if (q.cost && (e = hipMemsetAsync(q.cost, 0, (size_t)n_tiles * sizeof(uint32_t), stream)) != hipSuccess) return e;
     dim3 grid(n_blocks), block(kBlock);
-#define RT_LAUNCH(N, C, B) \
-    hipLaunchKernelGGL((path_kernel_persistent<N, C, B>), grid, block, 0, stream, sc, cam, rows, fr, q, n_frames)
+#define RT_LAUNCH(N, C, B)                                                                                             \
+    do {                                                                                                               \
+        if (pool_records)                                                                                              \
+            hipLaunchKernelGGL((path_kernel_pool<N, C, B>), grid, block, 0, stream, sc, cam, rows, fr, q, n_frames,    \
+                               static_cast<RayRecord*>(pool_records));                                                 \
+        else                                                                                                           \
+            hipLaunchKernelGGL((path_kernel_persistent<N, C, B>), grid, block, 0, stream, sc, cam, rows, fr, q,        \
+                               n_frames);                                                                              \
+    } while (0)
 #define RT_LAUNCH_NC(N, C) \
     do {                   \
         if (big) RT_LAUNCH(N, C, true); else RT_LAUNCH(N, C, false); \
@@ -897,10 +967,14 @@ uint32_t persistent_tile_count(const DevCam& cam, const DevRows& rows) {
     return ((cam.W + kPT - 1u) / kPT) * ((rows.local_rows + kPT - 1u) / kPT);
 }
 
-int persistent_blocks_per_cu(uint32_t stack_needed, bool count, bool big) {
+size_t pool_record_bytes(uint32_t n_blocks) { return (size_t)n_blocks * (kBlock / 64u) * kWaveSlots * sizeof(RayRecord); }
+
+int persistent_blocks_per_cu(uint32_t stack_needed, bool count, bool big, bool pool) {
     int n = 0;
     hipError_t e;
-#define RT_OCC(N, C, B) hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, path_kernel_persistent<N, C, B>, kBlock, 0)
+#define RT_OCC(N, C, B)                                                                                    \
+    (pool ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, path_kernel_pool<N, C, B>, kBlock, 0)         \
+          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, path_kernel_persistent<N, C, B>, kBlock, 0))
     if (stack_needed <= 32) {
         e = count ? (big ? RT_OCC(32, true, true) : RT_OCC(32, true, false))
                   : (big ? RT_OCC(32, false, true) : RT_OCC(32, false, false));

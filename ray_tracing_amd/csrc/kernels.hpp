@@ -21,7 +21,10 @@ hipError_t launch_path_kernel(const DevScene& sc, const DevCam& cam, const DevRo
 // order from an earlier launch.
 hipError_t launch_persistent_kernel(const DevScene& sc, const DevCam& cam, const DevRows& rows, const DevFrame& fr,
                                     DevQueue q, uint32_t* order_out, uint32_t n_frames, uint32_t stack_needed,
-                                    bool count, bool big, uint32_t n_blocks, hipStream_t stream);
+                                    bool count, bool big, uint32_t n_blocks, void* pool_records, hipStream_t stream);
+// `pool_records` != NULL runs the pooled form of the kernel (lanes only traverse; shading happens in
+// steps of its own over a pool of ray slots per wave): device memory of pool_record_bytes(n_blocks).
+size_t pool_record_bytes(uint32_t n_blocks);
 uint32_t persistent_tile_count(const DevCam& cam, const DevRows& rows);
 
 // Scratch of the no-allocation render entry point: a device array of the code object, one copy
@@ -41,6 +44,6 @@ hipError_t noalloc_scratch_init(int device);
 bool noalloc_scratch_view(int device, NoAllocView* out);
 
 // Workgroups of the persistent kernel one CU can hold (occupancy query).
-int persistent_blocks_per_cu(uint32_t stack_needed, bool count, bool big);
+int persistent_blocks_per_cu(uint32_t stack_needed, bool count, bool big, bool pool);
 
 }  // namespace rt

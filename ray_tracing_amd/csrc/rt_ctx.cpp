@@ -44,6 +44,8 @@ struct rt_ctx {
     uint32_t* d_tritests = nullptr;
     DevStats* d_stats = nullptr;
     uint32_t* d_queue = nullptr;  // work-queue heads of the persistent kernel
+    void* d_pool = nullptr;       // ray slots of the pooled kernel
+    size_t pool_bytes = 0;
     // cost-aware tile order: costs of the last launch, the order derived from them (two buffers:
     // one read by a launch, the other written after it), and the canvas partition they belong to
     uint32_t* d_tile_cost = nullptr;
@@ -54,11 +56,12 @@ struct rt_ctx {
     bool tile_order_enabled = true;
     int n_cus = 0;
     int vote_w[3] = {3, 2, 6};  // vote weights: control, box, triangle steps
+    uint32_t pool_slots = 0;     // RT_OPT_POOL_SLOTS
     int tile_deal = -1;          // -1: by launch length; 0 / 1: RT_OPT_TILE_DEAL
     int blocks_per_cu = 0;       // 0: as many as fit; RT_OPT_BLOCKS_PER_CU
     bool force_big_offsets = false;
     bool fast_div_enabled = true;
-    int per_cu_cache[2][2][2] = {{{0, 0}, {0, 0}}, {{0, 0}, {0, 0}}};  // occupancy answers, 0 = not asked yet
+    int per_cu_cache[2][2][2][2] = {};  // occupancy answers, 0 = not asked yet
 
     // options
     int pipeline = 1;
@@ -192,9 +195,9 @@ struct QueueBufs {
     uint32_t* order_sig = nullptr;
 };
 
-int blocks_per_cu(rt_ctx* c, uint32_t stack_needed, bool count, bool big) {
-    int& cached = c->per_cu_cache[stack_needed > 32 ? 1 : 0][count ? 1 : 0][big ? 1 : 0];
-    if (cached == 0) cached = persistent_blocks_per_cu(stack_needed, count, big);
+int blocks_per_cu(rt_ctx* c, uint32_t stack_needed, bool count, bool big, bool pool) {
+    int& cached = c->per_cu_cache[stack_needed > 32 ? 1 : 0][count ? 1 : 0][big ? 1 : 0][pool ? 1 : 0];
+    if (cached == 0) cached = persistent_blocks_per_cu(stack_needed, count, big, pool);
     int per_cu = cached;
     if (c->blocks_per_cu >= 1 && c->blocks_per_cu < per_cu) per_cu = c->blocks_per_cu;
     return per_cu;
@@ -299,6 +302,7 @@ int render(rt_ctx* c, const rt_cam_data& cam, uint32_t n_frames, const DevFrame*
         q.w_ctl = c->vote_w[0];
         q.w_box = c->vote_w[1];
         q.w_leaf = c->vote_w[2];
+        q.pool_slots = c->pool_slots;
         // the order this launch leaves behind is for the next launch, most likely one of the same length
         q.deal = c->tile_deal >= 0 ? (uint32_t)c->tile_deal : (n_frames <= 4u ? 1u : 0u);
         uint32_t* order_out = nullptr;
@@ -316,9 +320,18 @@ int render(rt_ctx* c, const rt_cam_data& cam, uint32_t n_frames, const DevFrame*
             // the buffer written below only counts as an order once every launch has been enqueued
             *qb.order_current = -1;
         }
-        const uint32_t n_blocks = (uint32_t)(c->n_cus * blocks_per_cu(c, stack_needed, count, big));
+        // the pooled form packs a pixel's coordinates into one word and is the context's own (it needs memory)
+        const bool pool = c->pipeline == 2 && own_buffers && dc.W < 65536u && dc.H < 65536u;
+        const uint32_t n_blocks = (uint32_t)(c->n_cus * blocks_per_cu(c, stack_needed, count, big, pool));
+        if (pool && pool_record_bytes(n_blocks) > c->pool_bytes) {
+            RT_HIP(c, hipStreamSynchronize(c->stream));
+            free_dev(c->d_pool);
+            c->pool_bytes = 0;
+            RT_HIP(c, hipMalloc(&c->d_pool, pool_record_bytes(n_blocks)));
+            c->pool_bytes = pool_record_bytes(n_blocks);
+        }
         RT_HIP(c, launch_persistent_kernel(sc, dc, rows, fr, q, order_out, n_frames, stack_needed, count, big, n_blocks,
-                                           c->stream));
+                                           pool ? c->d_pool : nullptr, c->stream));
         if (qb.cost && n_tiles != 0) *qb.order_current = next;
     }
     RT_HIP(c, hipEventRecord(c->ev1, c->stream));
@@ -371,6 +384,7 @@ void rt_destroy(rt_ctx* c) {
     free_frame(c);
     free_dev(c->d_stats);
     free_dev(c->d_queue);
+    free_dev(c->d_pool);
     free_dev(c->d_tile_cost);
     free_dev(c->d_tile_order[0]);
     free_dev(c->d_tile_order[1]);
@@ -394,7 +408,7 @@ int rt_set_option(rt_ctx* c, int option, int64_t value) {
     if (!c) return RT_ERR_INVALID;
     switch (option) {
         case RT_OPT_PIPELINE:
-            if (value < 0 || value > 1) return fail(c, RT_ERR_INVALID, "unknown pipeline");
+            if (value < 0 || value > 2) return fail(c, RT_ERR_INVALID, "unknown pipeline");
             c->pipeline = (int)value;
             return RT_OK;
         case RT_OPT_PROBE_HITS: c->probe_hits = value != 0; return RT_OK;
@@ -427,6 +441,10 @@ int rt_set_option(rt_ctx* c, int option, int64_t value) {
             return RT_OK;
         case RT_OPT_FORCE_BIG_OFFSETS: c->force_big_offsets = value != 0; return RT_OK;
         case RT_OPT_FAST_DIV: c->fast_div_enabled = value != 0; return RT_OK;
+        case RT_OPT_POOL_SLOTS:
+            if (value != 0 && (value < 64 || value > 192)) return fail(c, RT_ERR_INVALID, "pool slots: 0 (all) or 64..192");
+            c->pool_slots = (uint32_t)value;
+            return RT_OK;
         case RT_OPT_TILE_DEAL:
             if (value < -1 || value > 1) return fail(c, RT_ERR_INVALID, "tile deal: -1 (by launch length), 0 or 1");
             c->tile_deal = (int)value;
@@ -478,7 +496,7 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_info* info, const rt_vertex* verti
     // ask for the occupancy of the kernel variants this scene can launch now, so that a later
     // render call has nothing left to look up
     const uint32_t stack_needed = c->max_depth > 1 ? c->max_depth - 1 : 1;
-    for (int big = 0; big < 2; ++big) (void)blocks_per_cu(c, stack_needed, false, big != 0);
+    for (int big = 0; big < 2; ++big) (void)blocks_per_cu(c, stack_needed, false, big != 0, false);
     return RT_OK;
 }
 
@@ -670,6 +688,9 @@ int rt_get_sched_stats(rt_ctx* c, rt_sched_stats* out) {
         out->wait_cycles[k] = s.wait_cycles[k];
     }
     for (int k = 0; k < 8; ++k) out->site_wait_cycles[k] = s.site_wait[k];
+    out->shade_iterations = s.shade_iters;
+    out->shade_slots = s.shade_lanes;
+    out->shade_cycles = s.shade_cycles;
     return RT_OK;
 }
 

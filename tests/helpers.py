@@ -1,5 +1,6 @@
 """Helpers shared by the test modules."""
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -19,6 +20,9 @@ def gpu_render(scene, cam, frames, counters=True, materials=None, pipeline=1, op
     try:
         app.set_option(RT_OPT_PROBE_HITS, 1)
         app.set_option(RT_OPT_COUNTERS, int(counters))
+        # development hook: RT_TEST_PIPELINE=n runs every test that asks for the persistent kernel on kernel n
+        if pipeline == 1 and os.environ.get("RT_TEST_PIPELINE"):
+            pipeline = int(os.environ["RT_TEST_PIPELINE"])
         app.set_option(RT_OPT_PIPELINE, pipeline)
         for opt, value in options:
             app.set_option(opt, value)
