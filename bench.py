@@ -354,6 +354,9 @@ def main():
                          "kernel": "path_kernel_persistent" if args.pipeline else "path_kernel",
                          "kernel_ms": kernel_ms,
                          "valu_insts_per_launch": insts,
+                         # the same launch's vector instructions priced by class (2 / 4 / 8 SIMD cycles, the
+                         # probe's table) over its SIMD cycles; two bounds, see scripts/summarize_profile.py
+                         "valu_pipe_time_frac_bounds": prof.get("valu_pipe_time_frac_bounds") if world == 1 else None,
                          "probe": {"class": "v_mul_f32 / v_add_f32", "waves_per_simd": 4,
                                    "simd_cycles_per_inst": probe.simd_cycles_per_inst, "clock_mhz": probe.clock_mhz},
                          # the byte model of the reference's own data structures, and what reaches the

@@ -70,6 +70,13 @@ if "SQ_INSTS_VALU" in pmc and "GRBM_GUI_ACTIVE" in pmc:
         # what no class counter sees: min / max / med3, compares, selects, moves, lane reads
         d["valu_uncounted_share"] = 1.0 - (f32 + pmc["SQ_INSTS_VALU_TRANS_F32"] + pmc["SQ_INSTS_VALU_IOPS"]
                                            + pmc["SQ_INSTS_VALU_CVT"]) / pmc["SQ_INSTS_VALU"]
+        # Pipe time priced by class with the micro-probe's table (2 cycles: f32 add / mul / fma, integer
+        # add and logic; 8: transcendentals; 4: the rest).  The integer counters do not say which of
+        # their instructions are the 2-cycle ones, hence two bounds: all of them, or none.
+        trans = pmc["SQ_INSTS_VALU_TRANS_F32"]
+        ints = min(pmc["SQ_INSTS_VALU_INT32"] + pmc["SQ_INSTS_VALU_IOPS"], pmc["SQ_INSTS_VALU"] - f32 - trans)
+        d["valu_pipe_time_frac_low"] = (2 * (f32 + ints) + 8 * trans + 4 * (pmc["SQ_INSTS_VALU"] - f32 - ints - trans)) / simd_cycles
+        d["valu_pipe_time_frac_high"] = (2 * f32 + 8 * trans + 4 * (pmc["SQ_INSTS_VALU"] - f32 - trans)) / simd_cycles
 if "TCC_EA0_RDREQ_sum" in pmc:
     n32, n128 = pmc.get("TCC_EA0_RDREQ_32B_sum", 0), pmc.get("TCC_EA0_RDREQ_128B_sum", 0)
     n64 = pmc["TCC_EA0_RDREQ_sum"] - n32 - n128
@@ -105,6 +112,7 @@ if "bench_line_under_trace" in out and "l2_fabric_read_bytes" in d:
                "valu_insts_per_launch": pmc.get("SQ_INSTS_VALU"),
                "rays_per_launch": line["config"]["rays_per_step"],
                "simd_cycles_per_launch": d.get("simd_cycles"),
+               "valu_pipe_time_frac_bounds": [d.get("valu_pipe_time_frac_low"), d.get("valu_pipe_time_frac_high")],
                "source": f"profiles/{tag}_summary.json"}
     json.dump(traffic, open(os.path.join("profiles", "counters_bench.json"), "w"), indent=1)
 path = os.path.join("profiles", f"{tag}_summary.json")
