@@ -69,7 +69,12 @@ def canvas_for(name, world, scaling):
     return w, h
 
 
-def build_scene(name, leaf_max, threads, grid, canvas=None):
+BUILDERS = {"host": "BVH by the reference's split rule",
+            "gpu_sah": "BVH by binned surface-area splits on the GPU",
+            "gpu_linear": "linear BVH built on the GPU"}
+
+
+def build_scene(name, leaf_max, threads, grid, canvas=None, builder="host"):
     from ray_tracing_amd import sphere_field_scene, terrain_scene
 
     w, h, frames, depth, _ = CONFIGS[name]
@@ -80,18 +85,18 @@ def build_scene(name, leaf_max, threads, grid, canvas=None):
                                         leaf_max=leaf_max)
         what = "10000 tessellated spheres (icosphere, 320 triangles each), diffuse instance under the sky"
     elif name == "c3":
-        scene, cam = terrain_scene(w, h, n=grid, depth=depth, threads=threads, leaf_max=leaf_max)
+        scene, cam = terrain_scene(w, h, n=grid, depth=depth, threads=threads, leaf_max=leaf_max, builder=builder)
         what = "procedural terrain, 3 instances (glass / diffuse / emissive)"
     elif name == "c4":
         scene, cam = terrain_scene(w, h, n=2236 if grid == 700 else grid, depth=depth, threads=threads,
-                                   leaf_max=leaf_max)
+                                   leaf_max=leaf_max, builder=builder)
         what = "procedural terrain, 3 instances (glass / diffuse / emissive)"
     else:
         scene, cam = terrain_scene(w, h, n=grid, depth=depth, closed_box=True, light=False, threads=threads,
-                                   leaf_max=leaf_max)
+                                   leaf_max=leaf_max, builder=builder)
         what = "procedural terrain inside a closed box, diffuse only"
     workload = (f"{what}, {scene.n_triangles} triangles, {w}x{h}, {frames} spp per step, depth {depth}, "
-                f"BVH by the reference's split rule with leaves of at most {leaf_max} triangles")
+                f"{BUILDERS[builder]} with leaves of at most {leaf_max} triangles")
     return scene, cam, workload
 
 
@@ -128,6 +133,8 @@ def main():
     ap.add_argument("--grid", type=int, default=700, help="terrain grid resolution (700 -> ~1.0 M triangles)")
     ap.add_argument("--leaf-max", type=int, default=4,
                     help="largest leaf the BVH builder leaves unsplit (the reference's builder: 16, bvh.rs:75)")
+    ap.add_argument("--builder", choices=sorted(BUILDERS), default="host",
+                    help="who builds the big mesh's BVH: the reference's rule on the host (default) or a GPU builder")
     ap.add_argument("--pipeline", type=int, default=1, help="kernel: 0 plain nested loops, 1 persistent state machine")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="strong",
                     help="N > 1, tile-partitioned configs: strong = the config's own canvas (default), "
@@ -169,7 +176,7 @@ def main():
     width, height = canvas_for(args.config, world, args.scaling)
     scaling = "weak" if (args.scaling == "weak" and partition == "tile") else "strong"
     threads = max(1, min(os.cpu_count() or 1, 16) // max(1, world))
-    scene, cam0, workload = build_scene(args.config, args.leaf_max, threads, args.grid, (width, height))
+    scene, cam0, workload = build_scene(args.config, args.leaf_max, threads, args.grid, (width, height), args.builder)
     n_inst = int(scene.info.num_instances)
 
     stream = torch.cuda.current_stream().cuda_stream
@@ -307,6 +314,28 @@ def main():
         dt, rays, ms = timed(max(2, args.steps // 2), weak_step)
         extras["weak_scaling"] = {"canvas": [ww, wh], "Mrays_per_s": rays / dt / 1e6,
                                   "ms_per_step": dt / max(2, args.steps // 2) * 1e3}
+
+    if world == 1 and partition == "tile" and args.config == "c3" and args.builder == "host" and not args.no_extras:
+        # the same job on the tree the library's own GPU builder makes of the same mesh
+        t0 = time.perf_counter()
+        scene2, _, _ = build_scene(args.config, args.leaf_max, threads, args.grid, (width, height), "gpu_sah")
+        build_s = time.perf_counter() - t0
+        app2 = App.create(L.CamData.from_buffer_copy(cam0), scene2, device=device_index, stream=stream)
+        app2.set_option(RT_OPT_PIPELINE, args.pipeline)
+        app2.set_option(RT_OPT_PRESENT, args.present)
+        main_app, app = app, app2
+        try:
+            for _ in range(2):
+                one_step()
+            dt, rays, ms = timed(5, one_step)
+        finally:
+            app = main_app
+        extras["gpu_built_tree"] = {"builder": BUILDERS["gpu_sah"], "Mrays_per_s": rays / dt / 1e6,
+                                    "ms_per_step": dt / 5 * 1e3, "kernel_ms": ms,
+                                    "scene_build_s": build_s,
+                                    "what": "same scene, camera and frames; terrain tree from rt_create_bvh_device_sah "
+                                            "(scene_build_s covers mesh generation, the build and scene assembly)"}
+        app2.destroy()
 
     def committed_profile():
         """Per-launch hardware counters of this very workload from the committed rocprofv3 PMC

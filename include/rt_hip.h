@@ -228,6 +228,19 @@ int rt_create_bvh(const rt_vertex* vertices, size_t n_vertices, rt_tri* triangle
 int rt_create_bvh_device(int device, const rt_vertex* vertices, size_t n_vertices, rt_tri* triangles,
                          size_t n_triangles, uint32_t leaf_max, rt_bvh* nodes, size_t* n_nodes);
 
+/* A third builder, also on the GPU and also without a counterpart in the reference: top-down
+ * splits by the reference's own cost function (area(L) * |L| + area(R) * |R|, bvh.rs:109) and
+ * its rule "split while a node holds more than leaf_max triangles" (bvh.rs:75-94), the cost
+ * evaluated at 15 planes per axis between 16 bins of the node's centroid bounds, all nodes of a
+ * level at once.  Same contract and node format as rt_create_bvh_device; the same input always
+ * gives the same array.  `max_levels` bounds the number of node levels (0: 33, what the
+ * 32-entry traversal stack of the fast kernels takes; at most 65): a split that would leave a
+ * side too big for the levels that remain is replaced by a cut in the middle of the range.
+ * RT_ERR_LIMIT when leaf_max * 2^(max_levels - 1) < n_triangles. */
+int rt_create_bvh_device_sah(int device, const rt_vertex* vertices, size_t n_vertices, rt_tri* triangles,
+                             size_t n_triangles, uint32_t leaf_max, uint32_t max_levels, rt_bvh* nodes,
+                             size_t* n_nodes);
+
 /* SceneBuilder (mod.rs:38-134) */
 rt_scene_builder* rt_scene_builder_new(void);
 void rt_scene_builder_free(rt_scene_builder* b);
@@ -236,6 +249,13 @@ int rt_scene_builder_add_obj(rt_scene_builder* b, const char* text, size_t len,
 int rt_scene_builder_add_mesh(rt_scene_builder* b, const rt_vertex* vertices, size_t n_vertices,
                               const rt_tri* triangles, size_t n_triangles,
                               const rt_affine3a* transforms, size_t n_transforms, const rt_bvh_params* params);
+/* The same for a mesh whose tree is already built -- by rt_create_bvh, by one of the GPU builders
+ * or by the reference's own bvh::create_bvh: `triangles` in the tree's order, `nodes` with LOCAL
+ * indices and node 0 the root (what SceneBuilder::add_mesh, mod.rs:61-104, does after its call of
+ * create_bvh). */
+int rt_scene_builder_add_built_mesh(rt_scene_builder* b, const rt_vertex* vertices, size_t n_vertices,
+                                    const rt_tri* triangles, size_t n_triangles, const rt_bvh* nodes, size_t n_nodes,
+                                    const rt_affine3a* transforms, size_t n_transforms);
 void rt_scene_builder_sun_orientation(rt_scene_builder* b, float x, float y, float z);
 /* SceneBuilder::build: fills *info and hands out pointers that stay valid
  * until the builder is freed or extended. */

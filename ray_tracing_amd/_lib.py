@@ -148,10 +148,12 @@ SIGNATURES = {
     "rt_parse_obj": (_i32, [C.c_char_p, _sz, _vp, _P(_sz), _vp, _P(_sz)]),
     "rt_create_bvh": (_i32, [_vp, _sz, _vp, _sz, _P(BvhParams), _vp, _P(_sz)]),
     "rt_create_bvh_device": (_i32, [_i32, _vp, _sz, _vp, _sz, C.c_uint32, _vp, _P(_sz)]),
+    "rt_create_bvh_device_sah": (_i32, [_i32, _vp, _sz, _vp, _sz, C.c_uint32, C.c_uint32, _vp, _P(_sz)]),
     "rt_scene_builder_new": (_vp, []),
     "rt_scene_builder_free": (None, [_vp]),
     "rt_scene_builder_add_obj": (_i32, [_vp, C.c_char_p, _sz, _vp, _sz, _P(BvhParams)]),
     "rt_scene_builder_add_mesh": (_i32, [_vp, _vp, _sz, _vp, _sz, _vp, _sz, _P(BvhParams)]),
+    "rt_scene_builder_add_built_mesh": (_i32, [_vp, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _sz]),
     "rt_scene_builder_sun_orientation": (None, [_vp, _f, _f, _f]),
     "rt_scene_builder_build": (_i32, [_vp, _P(SceneInfo), _P(_vp), _P(_sz), _P(_vp), _P(_sz), _P(_vp), _P(_sz),
                                       _P(_vp), _P(_sz), _P(_vp), _P(_sz)]),

@@ -365,7 +365,13 @@ void SceneBuilder::add_mesh(std::vector<rt_vertex> mesh_vertices, std::vector<rt
                             const rt_affine3a* transforms, size_t n_transforms, const BvhBuildParams& params) {
     std::vector<rt_bvh> mesh_bvh =
         create_bvh(mesh_vertices.data(), mesh_vertices.size(), mesh_tris.data(), mesh_tris.size(), params);
+    add_built_mesh(mesh_vertices, mesh_tris, mesh_bvh, transforms, n_transforms);
+}
 
+// mod.rs:61-104: the mesh's indices move behind what the scene already holds
+void SceneBuilder::add_built_mesh(const std::vector<rt_vertex>& mesh_vertices, const std::vector<rt_tri>& mesh_tris,
+                                  const std::vector<rt_bvh>& mesh_bvh, const rt_affine3a* transforms,
+                                  size_t n_transforms) {
     const uint32_t vert_offset = uint32_t(vertices.size());
     const uint32_t bvh_offset = uint32_t(bvh.size());
     const uint32_t tri_offset = uint32_t(tris.size());

@@ -44,6 +44,9 @@ class SceneBuilder {
     SceneBuilder();
     void add_mesh(std::vector<rt_vertex> vertices, std::vector<rt_tri> tris, const rt_affine3a* transforms,
                   size_t n_transforms, const BvhBuildParams& params);
+    // a mesh whose tree is already built (LOCAL indices, node 0 the root, triangles in the tree's order)
+    void add_built_mesh(const std::vector<rt_vertex>& vertices, const std::vector<rt_tri>& tris,
+                        const std::vector<rt_bvh>& mesh_bvh, const rt_affine3a* transforms, size_t n_transforms);
     void add_obj_file(const char* text, size_t len, const rt_affine3a* transforms, size_t n_transforms,
                       const BvhBuildParams& params);
     void sun_orientation(float x, float y, float z);

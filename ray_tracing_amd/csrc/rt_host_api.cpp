@@ -100,6 +100,26 @@ int rt_scene_builder_add_mesh(rt_scene_builder* b, const rt_vertex* vertices, si
     return RT_OK;
 }
 
+int rt_scene_builder_add_built_mesh(rt_scene_builder* b, const rt_vertex* vertices, size_t n_vertices,
+                                    const rt_tri* triangles, size_t n_triangles, const rt_bvh* nodes, size_t n_nodes,
+                                    const rt_affine3a* transforms, size_t n_transforms) {
+    if (!b || !vertices || !triangles || !nodes || n_triangles == 0 || n_nodes == 0 || (n_transforms && !transforms))
+        return RT_ERR_INVALID;
+    if (!mesh_is_buildable(vertices, n_vertices, triangles, n_triangles)) return RT_ERR_INVALID;
+    // links must stay inside the mesh (rt_upload_scene checks the shape of the tree later)
+    for (size_t i = 0; i < n_nodes; ++i) {
+        const rt_bvh& nd = nodes[i];
+        const size_t limit = nd.mode == RT_MODE_CHILDREN ? n_nodes : n_triangles;
+        if (nd.mode != RT_MODE_CHILDREN && nd.mode != RT_MODE_TRIANGLES) return RT_ERR_INVALID;
+        if (nd.child_1_or_first_tri >= limit || nd.child_2_or_last_tri >= limit) return RT_ERR_INVALID;
+    }
+    std::vector<rt_vertex> v(vertices, vertices + n_vertices);
+    std::vector<rt_tri> f(triangles, triangles + n_triangles);
+    std::vector<rt_bvh> t(nodes, nodes + n_nodes);
+    b->sb.add_built_mesh(v, f, t, transforms, n_transforms);
+    return RT_OK;
+}
+
 void rt_scene_builder_sun_orientation(rt_scene_builder* b, float x, float y, float z) {
     if (b) b->sb.sun_orientation(x, y, z);
 }

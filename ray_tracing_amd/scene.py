@@ -88,21 +88,32 @@ def look_at(eye, target, up=(0.0, 1.0, 0.0)):
                                eye.astype(np.float32))
 
 
-def create_bvh_gpu(positions, triangles, leaf_max=4, device=0):
-    """Linear BVH built on the GPU (rt_create_bvh_device): returns the triangles in the order
-    the tree wants them and the nodes in the reference's 48-byte format (node 0 is the root)."""
+def create_bvh_gpu(positions, triangles, leaf_max=4, device=0, method="linear", max_levels=0):
+    """A BVH built on the GPU: returns the triangles in the order the tree wants them and the
+    nodes in the reference's 48-byte format (node 0 is the root).  method "linear": Morton-sorted
+    linear BVH (rt_create_bvh_device); "sah": binned surface-area splits by the reference's cost
+    function (rt_create_bvh_device_sah)."""
     lib = L.load()
     v = np.zeros(len(positions), VERTEX_DT)
     v["pos"] = np.ascontiguousarray(positions, np.float32)
     t = np.ascontiguousarray(triangles, np.uint32).copy()
     n = C.c_size_t(0)
-    rc = lib.rt_create_bvh_device(device, _ptr(v), len(v), _ptr(t), len(t), leaf_max, None, C.byref(n))
+    if method == "linear":
+        def call(nodes_ptr):
+            return lib.rt_create_bvh_device(device, _ptr(v), len(v), _ptr(t), len(t), leaf_max, nodes_ptr, C.byref(n))
+    elif method == "sah":
+        def call(nodes_ptr):
+            return lib.rt_create_bvh_device_sah(device, _ptr(v), len(v), _ptr(t), len(t), leaf_max, max_levels,
+                                                nodes_ptr, C.byref(n))
+    else:
+        raise ValueError(method)
+    rc = call(None)
     if rc != L.RT_OK:
-        raise L.RtError(rc, "rt_create_bvh_device: bad mesh")
+        raise L.RtError(rc, "GPU BVH builder: bad mesh")
     nodes = np.zeros(n.value, BVH_DT)
-    rc = lib.rt_create_bvh_device(device, _ptr(v), len(v), _ptr(t), len(t), leaf_max, _ptr(nodes), C.byref(n))
+    rc = call(_ptr(nodes))
     if rc != L.RT_OK:
-        raise L.RtError(rc, "rt_create_bvh_device failed (no GPU?)")
+        raise L.RtError(rc, "GPU BVH builder failed (no GPU?)")
     return t, nodes[:n.value].copy()
 
 
@@ -144,13 +155,23 @@ class SceneBuilder:
             raise L.RtError(rc, "rt_scene_builder_add_obj: unusable OBJ text")
         return self
 
-    def add_mesh(self, positions, triangles, transforms, params=None):
+    def add_mesh(self, positions, triangles, transforms, params=None, builder="host"):
+        """builder "host": the reference's split rule on the host (rt_create_bvh); "gpu_sah" /
+        "gpu_linear": one of the GPU builders, with the leaf size of `params`."""
         positions = np.ascontiguousarray(positions, np.float32)
         v = np.zeros(len(positions), VERTEX_DT)
         v["pos"] = positions
         t = np.ascontiguousarray(triangles, np.uint32)
         arr, n = self._xforms(transforms)
         p = params or bvh_params()
+        if builder != "host":
+            method = {"gpu_sah": "sah", "gpu_linear": "linear"}[builder]
+            t, nodes = create_bvh_gpu(positions, t, leaf_max=int(p.leaf_max), method=method)
+            rc = self._lib.rt_scene_builder_add_built_mesh(self._b, _ptr(v), len(v), _ptr(t), len(t), _ptr(nodes),
+                                                           len(nodes), arr, n)
+            if rc != L.RT_OK:
+                raise L.RtError(rc, "rt_scene_builder_add_built_mesh: bad mesh or tree")
+            return self
         rc = self._lib.rt_scene_builder_add_mesh(self._b, _ptr(v), len(v), _ptr(t), len(t), arr, n, C.byref(p))
         if rc != L.RT_OK:
             raise L.RtError(rc, "rt_scene_builder_add_mesh: bad mesh")
@@ -384,13 +405,14 @@ def sphere_field_scene(width=1920, height=1080, n_spheres=10000, seed=1, subdivi
 
 
 def terrain_scene(width=1920, height=1080, n=700, seed=2, depth=10, closed_box=False, threads=8, light=True,
-                  leaf_max=16):
+                  leaf_max=16, builder="host"):
     """~1M-triangle procedural terrain as instance 1 (diffuse), a glass cube as
     instance 0 and, with `light`, an emissive sphere as instance 2."""
     cv, cf, ct = _small_glass_cube(6.0, (10.0, 22.0, 5.0))
     tv, tf = terrain(n=n, seed=seed, closed_box=closed_box)
     ident = affine_from_srt((1, 1, 1), (0, 0, 0, 1), (0, 0, 0))
-    b = SceneBuilder().add_mesh(cv, cf, [ct]).add_mesh(tv, tf, [ident], bvh_params(leaf_max=leaf_max, threads=threads))
+    b = SceneBuilder().add_mesh(cv, cf, [ct]).add_mesh(tv, tf, [ident], bvh_params(leaf_max=leaf_max, threads=threads),
+                                                        builder=builder)
     if light:
         lv, lf = icosphere(2)
         b.add_mesh(lv.astype(np.float32), lf, [affine_from_srt((12.0,) * 3, (0, 0, 0, 1), (-30.0, 45.0, 20.0))])

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Build time and render throughput: the reference-rule host builder against the GPU linear BVH."""
+"""Build time and render throughput: the reference-rule host builder against the two GPU builders."""
 import os
 import sys
 import time
@@ -38,6 +38,12 @@ for leaf in (tuple(int(x) for x in sys.argv[2].split(",")) if len(sys.argv) > 2 
     tris, nodes = S.create_bvh_gpu(verts, faces, leaf_max=leaf)
     t_gpu = time.perf_counter() - t0
     print(f"GPU linear BVH, leaf {leaf}: {t_gpu * 1e3:.0f} ms (incl. transfers), {len(nodes)} nodes", flush=True)
+    render(S.single_object_scene(verts, tris, nodes, [ident]), "render")
+    S.create_bvh_gpu(verts[:3], np.array([[0, 1, 2]], np.uint32), method="sah")
+    t0 = time.perf_counter()
+    tris, nodes = S.create_bvh_gpu(verts, faces, leaf_max=leaf, method="sah")
+    t_gpu = time.perf_counter() - t0
+    print(f"GPU binned SAH, leaf {leaf}: {t_gpu * 1e3:.0f} ms (incl. transfers), {len(nodes)} nodes", flush=True)
     render(S.single_object_scene(verts, tris, nodes, [ident]), "render")
     t0 = time.perf_counter()
     b = S.SceneBuilder()

@@ -316,6 +316,55 @@ def test_gpu_built_bvh_of_a_million_triangles_is_exact_everywhere():
     assert (key(tris) == key(faces)).all(), "the triangles are not a permutation of the input"
 
 
+@pytest.mark.parametrize("leaf_max", [1, 4, 7])
+def test_gpu_built_sah_bvh_is_a_valid_tree_and_renders_like_the_oracle(leaf_max):
+    """rt_create_bvh_device_sah: binned surface-area splits on the GPU.  Like the linear BVH it
+    must be a proper BVH over a permutation of the input triangles with exact boxes, the kernels
+    must agree with the oracle on it, and the same input must give the same array twice."""
+    verts, faces = S.terrain(n=40)
+    faces = np.asarray(faces, np.uint32)
+    pos = np.asarray(verts, F)
+    tris, nodes = S.create_bvh_gpu(verts, faces, leaf_max=leaf_max, method="sah")
+    assert sorted(map(tuple, tris.tolist())) == sorted(map(tuple, faces.tolist()))
+    check_tree(nodes, len(tris), leaf_max)
+    assert check_tree_vectorised(nodes, tris, pos, leaf_max) <= 33
+    tris2, nodes2 = S.create_bvh_gpu(verts, faces, leaf_max=leaf_max, method="sah")
+    assert tris2.tobytes() == tris.tobytes() and nodes2.tobytes() == nodes.tobytes()
+    ident = S.affine_from_srt((1, 1, 1), (0, 0, 0, 1), (0, 0, 0))
+    shifted = S.affine_from_srt((0.5, 0.5, 0.5), S.quat_from_rotation("y", 0.7), (10, 25, 0))
+    scene = S.single_object_scene(pos, tris, nodes, [ident, shifted])
+    cam = S.make_cam(160, 90, S.look_at((60.0, 45.0, -70.0), (0.0, 0.0, 0.0)), fov=70.0, depth=4)
+    g, ref = check_against_oracle(scene, cam, frames=2)
+    assert (ref.hit_triangle != 0xFFFFFFFF).mean() > 0.3
+    # degenerate inputs: one triangle; many triangles with one and the same centroid (no plane
+    # separates them: cut by position); a level budget that forces cuts in the middle
+    one_t, one_n = S.create_bvh_gpu(pos[:3], np.array([[0, 1, 2]], np.uint32), leaf_max=4, method="sah")
+    assert len(one_n) == 1 and one_n[0]["mode"] == 1 and (one_n[0]["c1"], one_n[0]["c2"]) == (0, 0)
+    same = np.tile(np.array([[0, 1, 2]], np.uint32), (100, 1))
+    same_t, same_n = S.create_bvh_gpu(pos[:3], same, leaf_max=1, method="sah")
+    check_tree(same_n, 100, 1)
+    assert check_tree_vectorised(same_n, same_t, pos, 1) == 8  # 100 leaves of one: a balanced tree
+    need = int(np.ceil(np.log2(np.ceil(len(faces) / leaf_max)))) + 1
+    tight_t, tight_n = S.create_bvh_gpu(verts, faces, leaf_max=leaf_max, method="sah", max_levels=need)
+    assert check_tree_vectorised(tight_n, tight_t, pos, leaf_max) == need
+    with pytest.raises(L.RtError):
+        S.create_bvh_gpu(verts, faces, leaf_max=leaf_max, method="sah", max_levels=need - 1)
+
+
+def test_gpu_built_sah_bvh_of_a_million_triangles_is_exact_everywhere():
+    """The binned builder at the bench scene's size: every box of the whole tree against what it
+    must hold, the depth within what the 32-entry traversal stack takes."""
+    verts, faces = S.terrain(n=700)
+    pos = np.asarray(verts, F)
+    faces = np.asarray(faces, np.uint32)
+    for leaf_max in (4, 1, 16):
+        tris, nodes = S.create_bvh_gpu(verts, faces, leaf_max=leaf_max, method="sah")
+        assert len(tris) == len(faces)
+        assert check_tree_vectorised(nodes, tris, pos, leaf_max) <= 33
+    key = lambda t: np.sort(t[:, 0].astype(np.uint64) << np.uint64(42) | t[:, 1].astype(np.uint64) << np.uint64(21) | t[:, 2].astype(np.uint64))
+    assert (key(tris) == key(faces)).all(), "the triangles are not a permutation of the input"
+
+
 def parse_obj(name):
     data = S._resource(name).encode()
     lib = L.load()
