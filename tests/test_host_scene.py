@@ -314,6 +314,36 @@ def test_scene_builder_rejects_bad_input():
         b.add_obj_file("v 0 0 0\nv 1 0 0\nv 0 nan 0\nf 1 2 3\n", [ident])
 
 
+def test_a_ready_made_tree_goes_into_a_scene_like_one_built_in_place():
+    """rt_scene_builder_add_built_mesh with the tree rt_create_bvh makes of a mesh = add_mesh of that
+    mesh (the part of SceneBuilder::add_mesh after create_bvh, mod.rs:61-104); links that leave the
+    mesh are refused; the binned GPU builder refuses what the others refuse, without a GPU."""
+    verts, tris = random_soup(300, 4)
+    ident = S.affine_from_srt((1, 1, 1), (0, 0, 0, 1), (0, 0, 0))
+    moved = S.affine_from_srt((2, 2, 2), (0, 0, 0, 1), (5, 0, 0))
+    cube_v, cube_t = parse(S._resource("default_cube.obj"))
+    ref = S.SceneBuilder().add_mesh(cube_v, cube_t, [ident]).add_mesh(verts, tris, [ident, moved]).build()
+    nodes, ordered = lib_bvh(verts, tris)
+    vv = np.zeros(len(verts), S.VERTEX_DT)
+    vv["pos"] = verts
+    xf = (L.Affine3A * 2)(ident, moved)
+    b = S.SceneBuilder().add_mesh(cube_v, cube_t, [ident])
+    assert lib.rt_scene_builder_add_built_mesh(b._b, S._ptr(vv), len(vv), S._ptr(ordered), len(ordered), S._ptr(nodes),
+                                               len(nodes), xf, 2) == L.RT_OK
+    got = b.build()
+    for name in ("vertices", "triangles", "objects", "instances", "bvh"):
+        assert getattr(got, name).tobytes() == getattr(ref, name).tobytes(), name
+    bad = nodes.copy()
+    bad["c2"][0] = len(nodes) if bad["mode"][0] == 0 else len(ordered)
+    assert lib.rt_scene_builder_add_built_mesh(b._b, S._ptr(vv), len(vv), S._ptr(ordered), len(ordered), S._ptr(bad),
+                                               len(bad), xf, 2) == L.RT_ERR_INVALID
+    n = C.c_size_t(0)
+    tt = np.array([[0, 1, 9999]], np.uint32)
+    assert lib.rt_create_bvh_device_sah(0, S._ptr(vv), len(vv), S._ptr(tt), 1, 4, 0, None, C.byref(n)) == L.RT_ERR_INVALID
+    assert lib.rt_create_bvh_device_sah(0, S._ptr(vv), len(vv), S._ptr(ordered), len(ordered), 4, 0, None, C.byref(n)) == L.RT_OK
+    assert n.value == 2 * len(ordered) - 1  # the upper bound asked for with no node array
+
+
 # ------------------------------------------------------- arithmetic self-test ------
 def test_division_by_cached_reciprocal_is_the_ieee_quotient():
     """The slab test's six divisions share three divisors per traversal; the library forms the
