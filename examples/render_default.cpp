@@ -1,0 +1,124 @@
+// The reference's program (program/src/main.rs:18-149) over the C ABI of librt_hip.so, headless:
+// the start-up scene of main.rs:21-66 assembled by the library's SceneBuilder, the event loop's
+// render-and-advance turn (main.rs:129-149) run `frames` times, the image written as a PNG
+// instead of being copied to a swapchain.  Uses nothing but include/rt_hip.h.
+//
+//   render_default <resources dir> <out.png> [frames=64] [width=1280] [height=720] [acc.bin]
+//
+// With a sixth argument the raw accumulator (binding 7, RGBA32F) is written there as well.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iterator>
+#include <string>
+#include <vector>
+
+#include "../include/rt_hip.h"
+
+namespace {
+
+std::string slurp(const std::string& path) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) {
+        std::fprintf(stderr, "cannot read %s\n", path.c_str());
+        std::exit(2);
+    }
+    return std::string(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
+}
+
+void check(rt_ctx* ctx, int rc, const char* what) {
+    if (rc == RT_OK) return;
+    std::fprintf(stderr, "%s failed (%d): %s\n", what, rc, rt_last_error(ctx));
+    std::exit(1);
+}
+
+rt_affine3a srt(float sx, float sy, float sz, int axis, float angle, float tx, float ty, float tz) {
+    float scale[3] = {sx, sy, sz}, quat[4] = {0.0f, 0.0f, 0.0f, 1.0f}, trans[3] = {tx, ty, tz};
+    if (axis >= 0) rt_quat_from_rotation(axis, angle, quat);
+    rt_affine3a out;
+    rt_affine_from_srt(scale, quat, trans, &out);
+    return out;
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+    if (argc < 3) {
+        std::fprintf(stderr, "usage: %s <resources dir> <out.png> [frames] [width] [height] [acc.bin]\n", argv[0]);
+        return 2;
+    }
+    const std::string res = argv[1];
+    const unsigned frames = argc > 3 ? (unsigned)std::atoi(argv[3]) : 64u;
+    const unsigned width = argc > 4 ? (unsigned)std::atoi(argv[4]) : 1280u;
+    const unsigned height = argc > 5 ? (unsigned)std::atoi(argv[5]) : 720u;
+    const float pi = 3.14159265358979323846f;  // f32::consts::PI
+
+    // main.rs:21-34
+    rt_cam_data cam;
+    std::memset(&cam, 0, sizeof cam);
+    cam.transform = srt(1.0f, 1.0f, 1.0f, -1, 0.0f, 0.0f, 0.0f, -20.0f);
+    cam.canvas_width = width;
+    cam.canvas_height = height;
+    cam.fov = 90.0f;
+    cam.depth = 10;
+    cam.debug_number = 128;
+    cam.debug_information = RT_DEBUG_NONE;
+
+    // main.rs:36-66
+    const rt_affine3a teapot = srt(0.6f * 2.0f, 1.01f * 2.0f, 0.6f * 2.0f, 0, pi, 0.0f, -9.8f, 0.0f);
+    const rt_affine3a cube = srt(5.0f, 5.0f, 5.0f, 1, pi / 4.0f, 0.0f, 1.9f, 0.0f);
+    const rt_affine3a box = srt(10.0f, 10.0f, 10.0f, -1, 0.0f, 0.0f, 0.0f, 0.0f);
+    rt_scene_builder* sb = rt_scene_builder_new();
+    rt_bvh_params params;
+    rt_bvh_params_default(&params);
+    const struct {
+        const char* file;
+        const rt_affine3a* xf;
+    } meshes[3] = {{"default_cube.obj", &cube}, {"cornel_box.obj", &box}, {"teapot.obj", &teapot}};
+    for (const auto& m : meshes) {
+        const std::string text = slurp(res + "/" + m.file);
+        if (rt_scene_builder_add_obj(sb, text.data(), text.size(), m.xf, 1, &params) != RT_OK) {
+            std::fprintf(stderr, "unusable OBJ file %s\n", m.file);
+            return 1;
+        }
+    }
+    rt_scene_builder_sun_orientation(sb, 1.0f, -1.0f, 1.0f);
+    rt_scene_info info;
+    size_t nv = 0, nt = 0, nb = 0;
+    if (rt_scene_builder_build(sb, &info, nullptr, &nv, nullptr, &nt, nullptr, nullptr, nullptr, nullptr, nullptr, &nb) != RT_OK)
+        return 1;
+    std::printf("merged: %zu vertices, %zu triangles, %zu BVH nodes\n", nv, nt, nb);  // main.rs:68-73
+
+    rt_ctx* ctx = nullptr;
+    check(nullptr, rt_create(0, &ctx), "rt_create");
+    check(ctx, rt_upload_scene_from_builder(ctx, sb), "rt_upload_scene_from_builder");
+    rt_scene_builder_free(sb);
+
+    // the event loop's turn, main.rs:129-149: render, then frame += 1, frames_without_move += 1
+    float total_ms = 0.0f;
+    for (unsigned f = 0; f < frames; ++f) {
+        check(ctx, rt_render_frames(ctx, &cam, 1), "rt_render_frames");
+        check(ctx, rt_synchronize(ctx), "rt_synchronize");
+        float ms = 0.0f;
+        check(ctx, rt_last_render_ms(ctx, &ms), "rt_last_render_ms");
+        total_ms += ms;
+    }
+    std::printf("%u frames of %ux%u: %.3f ms per frame on the GPU (%.1f fps)\n", frames, width, height,
+                total_ms / (float)frames, 1000.0f * (float)frames / total_ms);
+
+    std::vector<float> image((size_t)width * height * 4);
+    check(ctx, rt_read_present(ctx, image.data(), (size_t)width * height), "rt_read_present");
+    if (rt_save_png(argv[2], image.data(), width, height) != RT_OK) {
+        std::fprintf(stderr, "cannot write %s\n", argv[2]);
+        return 1;
+    }
+    if (argc > 6) {
+        check(ctx, rt_read_acc(ctx, image.data(), (size_t)width * height), "rt_read_acc");
+        std::ofstream out(argv[6], std::ios::binary);
+        out.write(reinterpret_cast<const char*>(image.data()), (std::streamsize)(image.size() * sizeof(float)));
+    }
+    rt_destroy(ctx);
+    return 0;
+}
