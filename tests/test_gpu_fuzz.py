@@ -71,7 +71,7 @@ def random_mesh(rng, big=False):
     return np.asarray(v, F), np.asarray(f, np.uint32)
 
 
-def random_scene(rng, w, h, big=False, unit=1.0, kinds=REFERENCE_KINDS):
+def random_scene(rng, w, h, big=False, unit=1.0, kinds=REFERENCE_KINDS, builder="host"):
     """`unit` rescales object space (vertices by unit, instance scale by 1/unit): the same world-space
     scene, with object-space coordinates inside or outside the ranges the kernels' shortcuts accept."""
     b = S.SceneBuilder()
@@ -90,7 +90,7 @@ def random_scene(rng, w, h, big=False, unit=1.0, kinds=REFERENCE_KINDS):
                                                 [float(x) for x in rng.uniform(-3.0, 3.0, 3)]))
         params = S.bvh_params(leaf_max=int(rng.integers(1, 70 if big else 9)), root_leaf_max=int(rng.choice([0, 5, 100])),
                               max_depth=int(rng.choice([3, 32])), threads=1)
-        b.add_mesh(verts, idx, transforms, params)
+        b.add_mesh(verts, idx, transforms, params, builder=builder)
         n_instances += len(transforms)
     scene = b.build()
     eye = rng.uniform(-1.0, 1.0, 3)
@@ -156,3 +156,14 @@ def test_extra_random_scenes_on_request(seed):
     w, h = (int(rng.integers(40, 100)), int(rng.integers(30, 70))) if big else (int(rng.integers(5, 70)), int(rng.integers(5, 50)))
     unit = float(F(2.0) ** int(rng.choice([0, 0, 0, -30, -12, 12, 26, 30]))) if big else 1.0
     compare(*random_scene(rng, w, h, big=big, unit=unit, kinds=ALL_KINDS))
+
+
+@pytest.mark.parametrize("builder", ["gpu_sah", "gpu_linear"])
+@pytest.mark.parametrize("seed", range(12))
+def test_random_scene_on_a_gpu_built_tree_matches_the_oracle(seed, builder):
+    """The same random scenes with every mesh's tree built on the GPU: duplicated and zero-area
+    triangles, coincident centroids, flat boxes and rescaled object spaces go through the builders,
+    and the kernels must agree with the oracle on whatever tree comes out."""
+    rng = np.random.default_rng(7000 + seed)
+    unit = float(F(2.0) ** int(rng.choice([0, 0, -30, 12, 30])))
+    compare(*random_scene(rng, int(rng.integers(40, 110)), int(rng.integers(30, 80)), big=True, unit=unit, builder=builder))
