@@ -150,12 +150,14 @@ def test_random_scene_with_every_material_kind_matches_the_oracle(seed):
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("RT_FUZZ_EXTRA", "0"))))
 def test_extra_random_scenes_on_request(seed):
-    """A soak run: RT_FUZZ_EXTRA=n adds n more scenes (all material kinds, every fourth one large)."""
+    """A soak run: RT_FUZZ_EXTRA=n adds n more scenes (all material kinds, every fourth one large,
+    the trees by the host builder and the two GPU builders in turn)."""
     rng = np.random.default_rng(20000 + seed)
     big = seed % 4 == 3
+    builder = ("host", "gpu_sah", "gpu_linear")[(seed // 4) % 3]
     w, h = (int(rng.integers(40, 100)), int(rng.integers(30, 70))) if big else (int(rng.integers(5, 70)), int(rng.integers(5, 50)))
     unit = float(F(2.0) ** int(rng.choice([0, 0, 0, -30, -12, 12, 26, 30]))) if big else 1.0
-    compare(*random_scene(rng, w, h, big=big, unit=unit, kinds=ALL_KINDS))
+    compare(*random_scene(rng, w, h, big=big, unit=unit, kinds=ALL_KINDS, builder=builder))
 
 
 @pytest.mark.parametrize("builder", ["gpu_sah", "gpu_linear"])
