@@ -1,5 +1,5 @@
 #!/bin/bash
-# on the GPU box: one bench line per configuration DESIGN quotes, into gpurun_out/cfg_<name>.json
+# on the GPU box: one bench line per benchmark configuration (c2, c5, c3 with leaves of 16, c4), into gpurun_out/cfg_<name>.json
 set -u
 run() { # name, args...
   local n=$1; shift
