@@ -130,6 +130,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="c3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of host time the cpu_baseline leg may take")
     ap.add_argument("--grid", type=int, default=700, help="terrain grid resolution (700 -> ~1.0 M triangles)")
     ap.add_argument("--leaf-max", type=int, default=4,
                     help="largest leaf the BVH builder leaves unsplit (the reference's builder: 16, bvh.rs:75)")
@@ -400,7 +401,7 @@ def main():
         out.update(extras)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cam = L.CamData.from_buffer_copy(cam0)
-        out["cpu_baseline"] = cpu_baseline(scene, cam, frames_cap=max(frames_per_step, 64))
+        out["cpu_baseline"] = cpu_baseline(scene, cam, frames_cap=max(frames_per_step, 64), budget_s=args.cpu_budget)
     app.destroy()
     if world > 1:
         dist.barrier()
