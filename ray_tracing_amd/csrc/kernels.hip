@@ -811,7 +811,8 @@ __global__ __launch_bounds__(kBlock) void present_kernel(DevCam cam, DevRows row
 //     queue runs from the dearest tiles of the canvas to the cheapest and the launch ends on
 //     short pixels everywhere.  That shortens the tail, which is what a launch of one or two
 //     frames mostly consists of; over many frames the bands' locality is worth more.
-__global__ __launch_bounds__(kBlock) void order_tiles_kernel(DevQueue q, uint32_t* order_out) {
+constexpr int kOrderBlock = 1024;  // the sort is a chain of dependent passes over the costs: many threads, short chains
+__global__ __launch_bounds__(kOrderBlock) void order_tiles_kernel(DevQueue q, uint32_t* order_out) {
     __shared__ uint32_t s_count[32], s_start[32];
     const bool dealt = q.deal != 0u;
     const uint32_t t0 = dealt ? 0u : q.first_item[blockIdx.x] >> kPTShift;
@@ -820,7 +821,7 @@ __global__ __launch_bounds__(kBlock) void order_tiles_kernel(DevQueue q, uint32_
     __syncthreads();
     // a full tile's cost is 64 pixels x 1..10+ segments; 24 per class keeps the classes fine enough
     auto cls = [](uint32_t c) { return c * 64u / (kPT * kPT * 24u) < 31u ? c * 64u / (kPT * kPT * 24u) : 31u; };
-    for (uint32_t t = t0 + threadIdx.x; t < t1; t += kBlock) atomicAdd(&s_count[cls(q.cost[t])], 1u);
+    for (uint32_t t = t0 + threadIdx.x; t < t1; t += kOrderBlock) atomicAdd(&s_count[cls(q.cost[t])], 1u);
     __syncthreads();
     if (threadIdx.x == 0) {
         uint32_t at = 0;
@@ -830,7 +831,7 @@ __global__ __launch_bounds__(kBlock) void order_tiles_kernel(DevQueue q, uint32_
         }
     }
     __syncthreads();
-    for (uint32_t t = t0 + threadIdx.x; t < t1; t += kBlock) {
+    for (uint32_t t = t0 + threadIdx.x; t < t1; t += kOrderBlock) {
         const uint32_t r = atomicAdd(&s_start[cls(q.cost[t])], 1u);  // rank in the sorted order
         order_out[dealt ? (q.first_item[r & 7u] >> kPTShift) + (r >> 3) : t0 + r] = t;
     }
@@ -896,7 +897,7 @@ hipError_t launch_persistent_kernel(const DevScene& sc, const DevCam& cam, const
     hipError_t e2 = hipGetLastError();
     if (e2 != hipSuccess) return e2;
     if (q.cost && order_out) {
-        hipLaunchKernelGGL(order_tiles_kernel, dim3(q.deal ? 1 : 8), block, 0, stream, q, order_out);
+        hipLaunchKernelGGL(order_tiles_kernel, dim3(q.deal ? 1 : 8), dim3(kOrderBlock), 0, stream, q, order_out);
         if ((e2 = hipGetLastError()) != hipSuccess) return e2;
     }
     if (!fr.present) return hipSuccess;
