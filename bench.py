@@ -147,6 +147,11 @@ def main():
     ap.add_argument("--present", type=int, default=1, help="0: skip the gamma-corrected present image (accumulator only)")
     args = ap.parse_args()
 
+    if os.environ.get("RT_BENCH_WATCHDOG_S"):
+        # debugging aid: every rank dumps its Python stack to stderr and exits if it is still running then
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["RT_BENCH_WATCHDOG_S"]), exit=True)
+
     import torch
     import torch.distributed as dist
 

@@ -65,6 +65,12 @@ def reduce_samples(acc, group=None):
     import torch.distributed as dist
 
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        if acc.is_cuda and dist.get_backend(group) == "gloo":
+            # gloo stages device tensors through the host from a thread of its own; with the render
+            # kernel still in flight on the stream (two processes rehearsing on one GPU) that never
+            # returned.  RCCL needs no such wait: its kernel is ordered after the stream's work.
+            import torch
+            torch.cuda.current_stream(acc.device).synchronize()
         dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=group)
     return acc
 
