@@ -110,7 +110,7 @@ def compare(scene, cam, materials):
     if bool(np.isnan(ref.acc).any() or np.isnan(ref.hit_t_bits.view(F)).any()):
         frames = 1
         ref = O.OracleRenderer(scene, cam, trig=O.TRIG_DET, materials=materials).render(1)
-    for pipeline in (1, 0):
+    for pipeline in (1, 0, 2):  # persistent, plain, pooled persistent
         g = gpu_render(scene, cam, frames, materials=materials, pipeline=pipeline)
         tri, inst, tb = g["hits"]
         assert_bits_equal(tri, ref.hit_triangle, f"triangle_id (pipeline {pipeline})")

@@ -28,7 +28,7 @@ def c1():
     return default_scene(640, 360)
 
 
-@pytest.mark.parametrize("pipeline", [0, 1])
+@pytest.mark.parametrize("pipeline", [0, 1, 2])
 def test_default_scene_primary_hits_bit_exact(c1, pipeline):
     """Config 1: the reference's default scene at 640x360, frame 0, zeroed accumulator.
     Both kernel variants (plain nested loops, per-lane state machine)."""
@@ -45,7 +45,7 @@ def test_default_scene_primary_hits_bit_exact(c1, pipeline):
     assert g["stats"] == ref.stats_dict()
 
 
-@pytest.mark.parametrize("pipeline", [0, 1])
+@pytest.mark.parametrize("pipeline", [0, 1, 2])
 def test_default_scene_radiance_bit_exact_over_frames(c1, pipeline):
     """Four chained frames: every later seed hashes the previous accumulator bits
     (lib.rs:57-60), so a single differing bit anywhere would show."""
