@@ -155,7 +155,12 @@ int rt_synchronize(rt_ctx* ctx);
 /* ---- read-back.  n_pixels must be canvas_width*canvas_height of the last
  *      rendered frame.  Each call synchronises the stream. ---- */
 int rt_read_acc(rt_ctx* ctx, float* rgba, size_t n_pixels);     /* binding 7 */
-int rt_read_present(rt_ctx* ctx, float* rgba, size_t n_pixels); /* binding 8 */
+int rt_read_present(rt_ctx* ctx, float* rgba, size_t n_pixels);
+/* Binding 8 as the 8-bit image a display takes: R, G, B, A bytes per pixel, every channel clamped
+ * to [0, 1], times 255, rounded to nearest, NaN -> 0 -- what the reference's blit of the storage
+ * image into its B8G8R8A8 swapchain image does (vulkan.rs:1045-1101), converted on the GPU, so a
+ * frame costs 4 bytes per pixel over PCIe instead of 16.  Same bytes as rt_save_png writes. */
+int rt_read_present_rgba8(rt_ctx* ctx, uint8_t* rgba8, size_t n_pixels); /* binding 8 */
 int rt_write_acc(rt_ctx* ctx, const float* rgba, size_t n_pixels, uint32_t width, uint32_t height);
 /* Zero binding 7 on the device, as it is right after buffer creation. */
 int rt_clear_acc(rt_ctx* ctx);

@@ -135,6 +135,7 @@ SIGNATURES = {
     "rt_save_exr": (_i32, [C.c_char_p, _vp, C.c_uint32, C.c_uint32, C.c_float]),
     "rt_read_acc": (_i32, [_vp, _vp, _sz]),
     "rt_read_present": (_i32, [_vp, _vp, _sz]),
+    "rt_read_present_rgba8": (_i32, [_vp, _vp, _sz]),
     "rt_write_acc": (_i32, [_vp, _vp, _sz, _u32, _u32]),
     "rt_clear_acc": (_i32, [_vp]),
     "rt_read_hits": (_i32, [_vp, _vp, _vp, _vp, _sz]),

@@ -132,6 +132,12 @@ class App:
         self._check(self._lib.rt_read_present(self._ctx, _ptr(out), self._n()))
         return out
 
+    def read_present_rgba8(self):
+        """The displayed image as (H, W, 4) bytes, converted on the GPU (a quarter of the transfer)."""
+        out = np.empty((*self._shape(), 4), np.uint8)
+        self._check(self._lib.rt_read_present_rgba8(self._ctx, _ptr(out), self._n()))
+        return out
+
     # ---- image files, in place of the swapchain copy (vulkan.rs:1045-1101) ------
     def save_png(self, path):
         """The displayed image (binding 8) as an 8-bit PNG."""

@@ -802,6 +802,28 @@ __global__ __launch_bounds__(kBlock) void present_kernel(DevCam cam, DevRows row
     reinterpret_cast<float4*>(fr.present)[idx] = gamma_correct(present_from_acc(fwm_last, acc));
 }
 
+// The presented image as the 8-bit RGBA a display takes (what the reference's blit of binding 8
+// into the swapchain image produces, vulkan.rs:1045-1101): every channel clamped to [0, 1], times
+// 255, rounded to nearest; NaN -> 0.  The same rule as the PNG writer's, so the bytes agree.
+__global__ __launch_bounds__(kBlock) void present_bytes_kernel(const float4* present, uint32_t n, uint32_t* rgba8) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = present[i];
+    auto byte_of = [](float v) -> uint32_t {
+        if (!(v > 0.0f)) return 0u;
+        if (v >= 1.0f) return 255u;
+        return (uint32_t)__float2int_rn(v * 255.0f);
+    };
+    rgba8[i] = byte_of(p.x) | (byte_of(p.y) << 8) | (byte_of(p.z) << 16) | (byte_of(p.w) << 24);
+}
+
+hipError_t launch_present_bytes(const float* present, uint32_t n_pixels, uint32_t* rgba8, hipStream_t stream) {
+    if (n_pixels == 0) return hipSuccess;
+    hipLaunchKernelGGL(present_bytes_kernel, dim3((n_pixels + kBlock - 1) / kBlock), dim3(kBlock), 0, stream,
+                       reinterpret_cast<const float4*>(present), n_pixels, rgba8);
+    return hipGetLastError();
+}
+
 // Next launch's tile order from this launch's costs: a counting sort into 32 cost classes,
 // dearest class first.  Within a class the order is whatever the atomics make it: the order of
 // pixels changes no pixel's value.  Two ways of sharing the tiles out over the 8 queues:

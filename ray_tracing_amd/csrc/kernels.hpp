@@ -43,6 +43,9 @@ struct NoAllocView {
 hipError_t noalloc_scratch_init(int device);
 bool noalloc_scratch_view(int device, NoAllocView* out);
 
+// Binding 8 (RGBA32F) -> 8-bit RGBA, one word per pixel, R in the low byte.
+hipError_t launch_present_bytes(const float* present, uint32_t n_pixels, uint32_t* rgba8, hipStream_t stream);
+
 // Workgroups of the persistent kernel one CU can hold (occupancy query).
 int persistent_blocks_per_cu(uint32_t stack_needed, bool count, bool big, bool pool);
 

@@ -37,6 +37,7 @@ struct rt_ctx {
     uint32_t W = 0, H = 0;
     float* d_acc = nullptr;
     float* d_present = nullptr;
+    uint32_t* d_present8 = nullptr;  // rt_read_present_rgba8's staging, allocated on first use
     uint32_t* d_hit_tri = nullptr;
     uint32_t* d_hit_inst = nullptr;
     uint32_t* d_hit_t = nullptr;
@@ -109,6 +110,7 @@ void free_scene(rt_ctx* c) {
 void free_frame(rt_ctx* c) {
     free_dev(c->d_acc);
     free_dev(c->d_present);
+    free_dev(c->d_present8);
     free_dev(c->d_hit_tri);
     free_dev(c->d_hit_inst);
     free_dev(c->d_hit_t);
@@ -627,6 +629,18 @@ int rt_read_acc(rt_ctx* c, float* rgba, size_t n) { return read_back(c, rgba, c 
 
 int rt_read_present(rt_ctx* c, float* rgba, size_t n) {
     return read_back(c, rgba, c ? c->d_present : nullptr, n * 16, n, "present");
+}
+
+int rt_read_present_rgba8(rt_ctx* c, uint8_t* rgba8, size_t n) {
+    if (!c || !rgba8) return RT_ERR_INVALID;
+    if (!c->d_present) return fail(c, RT_ERR_INVALID, "present was never produced (option off or nothing rendered)");
+    if (n != (size_t)c->W * c->H) return fail(c, RT_ERR_INVALID, "n_pixels does not match the canvas");
+    RT_HIP(c, hipSetDevice(c->device));
+    if (!c->d_present8) RT_HIP(c, hipMalloc(&c->d_present8, n * 4));
+    RT_HIP(c, launch_present_bytes(c->d_present, (uint32_t)n, c->d_present8, c->stream));
+    RT_HIP(c, hipMemcpyAsync(rgba8, c->d_present8, n * 4, hipMemcpyDeviceToHost, c->stream));
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    return RT_OK;
 }
 
 int rt_write_acc(rt_ctx* c, const float* rgba, size_t n, uint32_t width, uint32_t height) {

@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""What a displayed frame costs beyond its render: reading the image back as floats and as bytes."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+from ray_tracing_amd import App  # noqa: E402
+from ray_tracing_amd import _lib as L  # noqa: E402
+
+scene, cam0, _ = bench.build_scene("c3", 4, 16, 700)
+app = App.create(L.CamData.from_buffer_copy(cam0), scene)
+for _ in range(3):
+    app.render_frames(1)
+app.synchronize()
+for name, fn in (("render + sync", lambda: (app.render_frames(1), app.synchronize())),
+                 ("read_present (RGBA32F, 33 MB)", app.read_present),
+                 ("read_present_rgba8 (8 MB)", app.read_present_rgba8)):
+    fn()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        fn()
+    print(f"{name}: {(time.perf_counter() - t0) / 20 * 1e3:.2f} ms", flush=True)
+app.destroy()

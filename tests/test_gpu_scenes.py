@@ -625,3 +625,19 @@ def test_tuning_options_change_no_pixel():
         for opt, bad in ((L.RT_OPT_VOTE_WEIGHTS, 0), (L.RT_OPT_BLOCKS_PER_CU, 9), (L.RT_OPT_TILE_DEAL, 2)):
             with pytest.raises(RtError):
                 app.set_option(opt, bad)
+
+
+def test_eight_bit_present_is_the_float_image_quantised_like_the_png_writer():
+    """rt_read_present_rgba8 converts binding 8 on the GPU: clamp to [0, 1], times 255, round to
+    nearest (even), NaN -> 0 -- the bytes rt_save_png derives from rt_read_present on the host."""
+    scene, cam = S.default_scene(333, 127)  # odd sizes: the last workgroup is partly empty
+    with App.create(cam, scene) as app:
+        with pytest.raises(L.RtError):
+            app.read_present_rgba8()  # nothing rendered yet
+        app.render_frames(3)
+        f = app.read_present()
+        b = app.read_present_rgba8()
+        again = app.read_present_rgba8()
+    want = np.where(f > 0, np.minimum(np.rint(np.minimum(f, F(1.0)) * F(255.0)), 255), 0).astype(np.uint8)
+    assert b.shape == (127, 333, 4) and np.array_equal(b, want) and np.array_equal(again, b)
+    assert b[..., :3].max() == 255 and 0 < b[..., :3].mean() < 255 and (b[..., 3] == 255).all()
