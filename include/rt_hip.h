@@ -160,7 +160,15 @@ int rt_read_present(rt_ctx* ctx, float* rgba, size_t n_pixels);
  * to [0, 1], times 255, rounded to nearest, NaN -> 0 -- what the reference's blit of the storage
  * image into its B8G8R8A8 swapchain image does (vulkan.rs:1045-1101), converted on the GPU, so a
  * frame costs 4 bytes per pixel over PCIe instead of 16.  Same bytes as rt_save_png writes. */
-int rt_read_present_rgba8(rt_ctx* ctx, uint8_t* rgba8, size_t n_pixels); /* binding 8 */
+int rt_read_present_rgba8(rt_ctx* ctx, uint8_t* rgba8, size_t n_pixels);
+/* The same image without stopping the renderer (no counterpart in the reference, whose render waits
+ * on its fence every frame, vulkan.rs:171-236): rt_present_begin, called after a render, enqueues the
+ * quantisation and a copy into pinned memory of the library's on a stream of its own and returns;
+ * the caller may enqueue the next render at once; rt_present_end waits for the copy and hands out
+ * the bytes (W * H * 4, valid until the next rt_present_begin, a change of canvas size or
+ * rt_destroy).  The copy of frame k then overlaps the render of frame k + 1. */
+int rt_present_begin(rt_ctx* ctx);
+int rt_present_end(rt_ctx* ctx, const uint8_t** rgba8, size_t* n_pixels); /* binding 8 */
 int rt_write_acc(rt_ctx* ctx, const float* rgba, size_t n_pixels, uint32_t width, uint32_t height);
 /* Zero binding 7 on the device, as it is right after buffer creation. */
 int rt_clear_acc(rt_ctx* ctx);

@@ -136,6 +136,8 @@ SIGNATURES = {
     "rt_read_acc": (_i32, [_vp, _vp, _sz]),
     "rt_read_present": (_i32, [_vp, _vp, _sz]),
     "rt_read_present_rgba8": (_i32, [_vp, _vp, _sz]),
+    "rt_present_begin": (_i32, [_vp]),
+    "rt_present_end": (_i32, [_vp, _P(_vp), _P(_sz)]),
     "rt_write_acc": (_i32, [_vp, _vp, _sz, _u32, _u32]),
     "rt_clear_acc": (_i32, [_vp]),
     "rt_read_hits": (_i32, [_vp, _vp, _vp, _vp, _sz]),

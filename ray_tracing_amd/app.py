@@ -138,6 +138,19 @@ class App:
         self._check(self._lib.rt_read_present_rgba8(self._ctx, _ptr(out), self._n()))
         return out
 
+    def present_begin(self):
+        """Start quantising and copying the displayed image; returns at once (see present_end)."""
+        self._check(self._lib.rt_present_begin(self._ctx))
+
+    def present_end(self):
+        """Wait for the copy present_begin started; (H, W, 4) bytes (a copy of the library's buffer)."""
+        p, n = C.c_void_p(), C.c_size_t()
+        self._check(self._lib.rt_present_end(self._ctx, C.byref(p), C.byref(n)))
+        h, w = self._shape()
+        assert n.value == h * w
+        buf = (C.c_uint8 * (n.value * 4)).from_address(p.value)
+        return np.frombuffer(buf, np.uint8).reshape(h, w, 4).copy()
+
     # ---- image files, in place of the swapchain copy (vulkan.rs:1045-1101) ------
     def save_png(self, path):
         """The displayed image (binding 8) as an 8-bit PNG."""

@@ -37,7 +37,13 @@ struct rt_ctx {
     uint32_t W = 0, H = 0;
     float* d_acc = nullptr;
     float* d_present = nullptr;
-    uint32_t* d_present8 = nullptr;  // rt_read_present_rgba8's staging, allocated on first use
+    uint32_t* d_present8 = nullptr;  // the 8-bit image on the device, allocated on first use
+    // rt_present_begin / rt_present_end: the copy of the 8-bit image to the host runs on a stream
+    // of its own, so that it overlaps the next render
+    uint8_t* h_present8 = nullptr;  // pinned
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_quantised = nullptr, ev_copied = nullptr;
+    bool copy_pending = false;
     uint32_t* d_hit_tri = nullptr;
     uint32_t* d_hit_inst = nullptr;
     uint32_t* d_hit_t = nullptr;
@@ -108,6 +114,12 @@ void free_scene(rt_ctx* c) {
 }
 
 void free_frame(rt_ctx* c) {
+    if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);  // a copy may still read d_present8
+    c->copy_pending = false;
+    if (c->h_present8) {
+        (void)hipHostFree(c->h_present8);
+        c->h_present8 = nullptr;
+    }
     free_dev(c->d_acc);
     free_dev(c->d_present);
     free_dev(c->d_present8);
@@ -390,6 +402,9 @@ void rt_destroy(rt_ctx* c) {
     free_dev(c->d_tile_cost);
     free_dev(c->d_tile_order[0]);
     free_dev(c->d_tile_order[1]);
+    if (c->ev_quantised) (void)hipEventDestroy(c->ev_quantised);
+    if (c->ev_copied) (void)hipEventDestroy(c->ev_copied);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     delete c;
@@ -631,15 +646,52 @@ int rt_read_present(rt_ctx* c, float* rgba, size_t n) {
     return read_back(c, rgba, c ? c->d_present : nullptr, n * 16, n, "present");
 }
 
+// Binding 8 quantised into d_present8, enqueued on the render stream (after any copy that still
+// reads the buffer).
+static int quantise_present(rt_ctx* c) {
+    if (!c->d_present) return fail(c, RT_ERR_INVALID, "present was never produced (option off or nothing rendered)");
+    RT_HIP(c, hipSetDevice(c->device));
+    const size_t n = (size_t)c->W * c->H;
+    if (!c->d_present8) RT_HIP(c, hipMalloc(&c->d_present8, n * 4));
+    if (c->copy_pending) RT_HIP(c, hipStreamWaitEvent(c->stream, c->ev_copied, 0));
+    RT_HIP(c, launch_present_bytes(c->d_present, (uint32_t)n, c->d_present8, c->stream));
+    return RT_OK;
+}
+
 int rt_read_present_rgba8(rt_ctx* c, uint8_t* rgba8, size_t n) {
     if (!c || !rgba8) return RT_ERR_INVALID;
-    if (!c->d_present) return fail(c, RT_ERR_INVALID, "present was never produced (option off or nothing rendered)");
     if (n != (size_t)c->W * c->H) return fail(c, RT_ERR_INVALID, "n_pixels does not match the canvas");
-    RT_HIP(c, hipSetDevice(c->device));
-    if (!c->d_present8) RT_HIP(c, hipMalloc(&c->d_present8, n * 4));
-    RT_HIP(c, launch_present_bytes(c->d_present, (uint32_t)n, c->d_present8, c->stream));
+    const int rc = quantise_present(c);
+    if (rc != RT_OK) return rc;
     RT_HIP(c, hipMemcpyAsync(rgba8, c->d_present8, n * 4, hipMemcpyDeviceToHost, c->stream));
     RT_HIP(c, hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+int rt_present_begin(rt_ctx* c) {
+    if (!c) return RT_ERR_INVALID;
+    int rc = quantise_present(c);
+    if (rc != RT_OK) return rc;
+    const size_t n = (size_t)c->W * c->H;
+    if (!c->copy_stream) RT_HIP(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    if (!c->ev_quantised) RT_HIP(c, hipEventCreateWithFlags(&c->ev_quantised, hipEventDisableTiming));
+    if (!c->ev_copied) RT_HIP(c, hipEventCreateWithFlags(&c->ev_copied, hipEventDisableTiming));
+    if (!c->h_present8) RT_HIP(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_present8), n * 4, hipHostMallocDefault));
+    RT_HIP(c, hipEventRecord(c->ev_quantised, c->stream));
+    RT_HIP(c, hipStreamWaitEvent(c->copy_stream, c->ev_quantised, 0));
+    RT_HIP(c, hipMemcpyAsync(c->h_present8, c->d_present8, n * 4, hipMemcpyDeviceToHost, c->copy_stream));
+    RT_HIP(c, hipEventRecord(c->ev_copied, c->copy_stream));
+    c->copy_pending = true;
+    return RT_OK;
+}
+
+int rt_present_end(rt_ctx* c, const uint8_t** rgba8, size_t* n_pixels) {
+    if (!c || !rgba8) return RT_ERR_INVALID;
+    if (!c->copy_pending) return fail(c, RT_ERR_INVALID, "rt_present_begin has not been called for this canvas");
+    RT_HIP(c, hipSetDevice(c->device));
+    RT_HIP(c, hipEventSynchronize(c->ev_copied));
+    *rgba8 = c->h_present8;
+    if (n_pixels) *n_pixels = (size_t)c->W * c->H;
     return RT_OK;
 }
 

@@ -641,3 +641,27 @@ def test_eight_bit_present_is_the_float_image_quantised_like_the_png_writer():
     want = np.where(f > 0, np.minimum(np.rint(np.minimum(f, F(1.0)) * F(255.0)), 255), 0).astype(np.uint8)
     assert b.shape == (127, 333, 4) and np.array_equal(b, want) and np.array_equal(again, b)
     assert b[..., :3].max() == 255 and 0 < b[..., :3].mean() < 255 and (b[..., 3] == 255).all()
+
+
+def test_present_begin_end_hands_out_the_frame_it_was_started_for():
+    """rt_present_begin / rt_present_end: the copy of frame k runs beside the render of frame k + 1 and
+    must still be frame k; a second begin waits for the first copy before it reuses the buffers."""
+    scene, cam = S.default_scene(320, 180)
+    with App.create(copy_cam(cam), scene) as ref:
+        frames = []
+        for _ in range(3):
+            ref.render_frames(1)
+            frames.append(ref.read_present_rgba8())
+    assert not np.array_equal(frames[0], frames[1])
+    with App.create(copy_cam(cam), scene) as app:
+        with pytest.raises(L.RtError):
+            app.present_end()  # nothing begun
+        app.render_frames(1)
+        app.present_begin()
+        app.render_frames(1)  # enqueued behind the quantisation, beside the copy
+        assert np.array_equal(app.present_end(), frames[0])
+        app.present_begin()
+        app.render_frames(1)
+        app.present_begin()  # frame 3 before frame 2 was asked for: waits for that copy, then replaces it
+        assert np.array_equal(app.present_end(), frames[2])
+        assert np.array_equal(app.read_present_rgba8(), frames[2])
