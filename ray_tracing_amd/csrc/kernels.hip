@@ -825,25 +825,29 @@ hipError_t launch_present_bytes(const float* present, uint32_t n_pixels, uint32_
 }
 
 // Next launch's tile order from this launch's costs: a counting sort into 32 cost classes,
-// dearest class first.  Within a class the order is whatever the atomics make it: the order of
-// pixels changes no pixel's value.  Two ways of sharing the tiles out over the 8 queues:
-//   banded (8 workgroups, one per queue): every queue keeps its contiguous band of the canvas --
-//     an XCD's L2 keeps seeing neighbouring rays -- and sorts the tiles inside it;
-//   dealt (1 workgroup): all tiles are sorted together and dealt to the queues in turn, so every
-//     queue runs from the dearest tiles of the canvas to the cheapest and the launch ends on
+// dearest class first, one workgroup per queue.  Within a class the order is whatever the atomics
+// make it: the order of pixels changes no pixel's value.  Two ways of sharing the tiles out over
+// the 8 queues:
+//   banded: every queue keeps its contiguous band of the canvas -- an XCD's L2 keeps seeing
+//     neighbouring rays -- and sorts the tiles inside it;
+//   dealt: queue i takes every eighth tile of the whole canvas (i, i + 8, ...), so every queue is
+//     a sample of all of it, runs from its dearest tiles to its cheapest and the launch ends on
 //     short pixels everywhere.  That shortens the tail, which is what a launch of one or two
 //     frames mostly consists of; over many frames the bands' locality is worth more.
 constexpr int kOrderBlock = 1024;  // the sort is a chain of dependent passes over the costs: many threads, short chains
 __global__ __launch_bounds__(kOrderBlock) void order_tiles_kernel(DevQueue q, uint32_t* order_out) {
     __shared__ uint32_t s_count[32], s_start[32];
+    // this workgroup's queue takes a contiguous band of the canvas, or every eighth tile of all of it
     const bool dealt = q.deal != 0u;
-    const uint32_t t0 = dealt ? 0u : q.first_item[blockIdx.x] >> kPTShift;
+    const uint32_t base = q.first_item[blockIdx.x] >> kPTShift;  // where the queue's part of the order begins
+    const uint32_t t0 = dealt ? blockIdx.x : base;
     const uint32_t t1 = (dealt ? q.first_item[8] : q.first_item[blockIdx.x + 1]) >> kPTShift;
+    const uint32_t step = dealt ? 8u : 1u;
     if (threadIdx.x < 32) s_count[threadIdx.x] = 0;
     __syncthreads();
     // a full tile's cost is 64 pixels x 1..10+ segments; 24 per class keeps the classes fine enough
     auto cls = [](uint32_t c) { return c * 64u / (kPT * kPT * 24u) < 31u ? c * 64u / (kPT * kPT * 24u) : 31u; };
-    for (uint32_t t = t0 + threadIdx.x; t < t1; t += kOrderBlock) atomicAdd(&s_count[cls(q.cost[t])], 1u);
+    for (uint32_t t = t0 + threadIdx.x * step; t < t1; t += kOrderBlock * step) atomicAdd(&s_count[cls(q.cost[t])], 1u);
     __syncthreads();
     if (threadIdx.x == 0) {
         uint32_t at = 0;
@@ -853,9 +857,9 @@ __global__ __launch_bounds__(kOrderBlock) void order_tiles_kernel(DevQueue q, ui
         }
     }
     __syncthreads();
-    for (uint32_t t = t0 + threadIdx.x; t < t1; t += kOrderBlock) {
+    for (uint32_t t = t0 + threadIdx.x * step; t < t1; t += kOrderBlock * step) {
         const uint32_t r = atomicAdd(&s_start[cls(q.cost[t])], 1u);  // rank in the sorted order
-        order_out[dealt ? (q.first_item[r & 7u] >> kPTShift) + (r >> 3) : t0 + r] = t;
+        order_out[base + r] = t;
     }
 }
 
@@ -919,7 +923,7 @@ hipError_t launch_persistent_kernel(const DevScene& sc, const DevCam& cam, const
     hipError_t e2 = hipGetLastError();
     if (e2 != hipSuccess) return e2;
     if (q.cost && order_out) {
-        hipLaunchKernelGGL(order_tiles_kernel, dim3(q.deal ? 1 : 8), dim3(kOrderBlock), 0, stream, q, order_out);
+        hipLaunchKernelGGL(order_tiles_kernel, dim3(8), dim3(kOrderBlock), 0, stream, q, order_out);
         if ((e2 = hipGetLastError()) != hipSuccess) return e2;
     }
     if (!fr.present) return hipSuccess;
