@@ -82,7 +82,7 @@ def build_scene(name, leaf_max, threads, grid, canvas=None, builder="host"):
         w, h = canvas
     if name == "c2":
         scene, cam = sphere_field_scene(w, h, n_spheres=10000, seed=1, subdivisions=2, depth=depth, threads=threads,
-                                        leaf_max=leaf_max)
+                                        leaf_max=leaf_max, builder=builder)
         what = "10000 tessellated spheres (icosphere, 320 triangles each), diffuse instance under the sky"
     elif name == "c3":
         scene, cam = terrain_scene(w, h, n=grid, depth=depth, threads=threads, leaf_max=leaf_max, builder=builder)

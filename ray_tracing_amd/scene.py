@@ -392,14 +392,14 @@ def _small_glass_cube(scale, translation):
 
 
 def sphere_field_scene(width=1920, height=1080, n_spheres=10000, seed=1, subdivisions=2, depth=5, threads=8,
-                       rmin=0.3, rmax=1.0, leaf_max=16):
+                       rmin=0.3, rmax=1.0, leaf_max=16, builder="host"):
     """10k tessellated spheres under the sky, all in instance 1 (the diffuse
     NormalMaterial); instance 0 is a small glass cube at the centre."""
     cv, cf, ct = _small_glass_cube(2.0, (0.0, 0.0, 0.0))
     sv, sf = sphere_field(n_spheres, seed, subdivisions, rmin=rmin, rmax=rmax)
     ident = affine_from_srt((1, 1, 1), (0, 0, 0, 1), (0, 0, 0))
     scene = (SceneBuilder().add_mesh(cv, cf, [ct])
-             .add_mesh(sv, sf, [ident], bvh_params(leaf_max=leaf_max, threads=threads)).build())
+             .add_mesh(sv, sf, [ident], bvh_params(leaf_max=leaf_max, threads=threads), builder=builder).build())
     cam = make_cam(width, height, affine_from_srt((1, 1, 1), (0, 0, 0, 1), (0.0, 0.0, -115.0)), depth=depth)
     return scene, cam
 
