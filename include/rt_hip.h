@@ -249,7 +249,9 @@ int rt_create_bvh_device(int device, const rt_vertex* vertices, size_t n_vertice
  * gives the same array.  `max_levels` bounds the number of node levels (0: 33, what the
  * 32-entry traversal stack of the fast kernels takes; at most 65): a split that would leave a
  * side too big for the levels that remain is replaced by a cut in the middle of the range.
- * RT_ERR_LIMIT when leaf_max * 2^(max_levels - 1) < n_triangles. */
+ * When leaf_max * 2^(max_levels - 1) < n_triangles no tree of that many levels has leaves that
+ * small: the nodes of the last level then stay leaves whatever they hold, as the reference's
+ * nodes do at MAX_DEPTH (bvh.rs:75, 85). */
 int rt_create_bvh_device_sah(int device, const rt_vertex* vertices, size_t n_vertices, rt_tri* triangles,
                              size_t n_triangles, uint32_t leaf_max, uint32_t max_levels, rt_bvh* nodes,
                              size_t* n_nodes);
@@ -262,6 +264,14 @@ int rt_scene_builder_add_obj(rt_scene_builder* b, const char* text, size_t len,
 int rt_scene_builder_add_mesh(rt_scene_builder* b, const rt_vertex* vertices, size_t n_vertices,
                               const rt_tri* triangles, size_t n_triangles,
                               const rt_affine3a* transforms, size_t n_transforms, const rt_bvh_params* params);
+/* Which builder the meshes added from now on get their tree from: the reference's rule on the host
+ * (the default), or one of the GPU builders on `device` (ignored for RT_BVH_HOST), with the leaf
+ * size and root rule of the rt_bvh_params passed with the mesh and max_depth + 1 levels.  The
+ * add calls then return whatever the GPU builder returns (RT_ERR_HIP without a GPU). */
+#define RT_BVH_HOST 0
+#define RT_BVH_DEVICE_LINEAR 1
+#define RT_BVH_DEVICE_SAH 2
+int rt_scene_builder_use_bvh_builder(rt_scene_builder* b, int method, int device);
 /* The same for a mesh whose tree is already built -- by rt_create_bvh, by one of the GPU builders
  * or by the reference's own bvh::create_bvh: `triangles` in the tree's order, `nodes` with LOCAL
  * indices and node 0 the root (what SceneBuilder::add_mesh, mod.rs:61-104, does after its call of

@@ -103,6 +103,7 @@ RT_OPT_PIPELINE, RT_OPT_PROBE_HITS, RT_OPT_COUNTERS, RT_OPT_PRESENT = 1, 2, 3, 4
 RT_OPT_FRAME_STRIDE, RT_OPT_SEED_MODE = 5, 6
 RT_OPT_TILE_ORDER, RT_OPT_VOTE_WEIGHTS, RT_OPT_BLOCKS_PER_CU = 7, 8, 9
 RT_OPT_FORCE_BIG_OFFSETS, RT_OPT_FAST_DIV, RT_OPT_TILE_DEAL, RT_OPT_POOL_SLOTS = 10, 11, 12, 13
+RT_BVH_HOST, RT_BVH_DEVICE_LINEAR, RT_BVH_DEVICE_SAH = 0, 1, 2
 RT_MAT_GENERIC, RT_MAT_NORMAL, RT_MAT_EMISSIVE = 0, 1, 2
 RT_MAT_REFRACTIVE, RT_MAT_UV, RT_MAT_DIFFUSE, RT_MAT_METAL = 3, 4, 5, 6
 RT_DEBUG_NONE, RT_DEBUG_TRIANGLE_INTERSECTION, RT_DEBUG_BVH_INTERSECTION = 0, 1, 2
@@ -156,6 +157,7 @@ SIGNATURES = {
     "rt_scene_builder_free": (None, [_vp]),
     "rt_scene_builder_add_obj": (_i32, [_vp, C.c_char_p, _sz, _vp, _sz, _P(BvhParams)]),
     "rt_scene_builder_add_mesh": (_i32, [_vp, _vp, _sz, _vp, _sz, _vp, _sz, _P(BvhParams)]),
+    "rt_scene_builder_use_bvh_builder": (_i32, [_vp, _i32, _i32]),
     "rt_scene_builder_add_built_mesh": (_i32, [_vp, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _sz]),
     "rt_scene_builder_sun_orientation": (None, [_vp, _f, _f, _f]),
     "rt_scene_builder_build": (_i32, [_vp, _P(SceneInfo), _P(_vp), _P(_sz), _P(_vp), _P(_sz), _P(_vp), _P(_sz),

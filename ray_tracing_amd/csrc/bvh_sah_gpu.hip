@@ -432,13 +432,6 @@ extern "C" int rt_create_bvh_device_sah(int device, const rt_vertex* vertices, s
         *n_nodes = total;
         return RT_OK;
     }
-    // the levels must be able to hold the triangles at all
-    {
-        uint64_t room = leaf_max;
-        for (uint32_t l = 1; l < max_levels && room < n; ++l) room *= 2;
-        if (room < n) return RT_ERR_LIMIT;
-    }
-
     int n_dev = 0;
     if (hipGetDeviceCount(&n_dev) != hipSuccess || device < 0 || device >= n_dev) return RT_ERR_HIP;
     RT_TRY(hipSetDevice(device));

@@ -1,5 +1,6 @@
 // The host half of the C ABI (include/rt_hip.h): OBJ parsing, BVH build, scene
-// assembly and the camera helpers.  No GPU calls in this file.
+// assembly and the camera helpers.  No GPU calls in this file (a scene builder told to use a GPU
+// BVH builder calls the library's own rt_create_bvh_device / rt_create_bvh_device_sah).
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -14,9 +15,32 @@ using namespace rt;
 
 struct rt_scene_builder {
     SceneBuilder sb;
+    int bvh_device = -1;  // >= 0: meshes get their tree from a GPU builder on that device
+    int bvh_method = RT_BVH_HOST;
 };
 
 namespace {
+
+// One mesh into the scene, its tree by whichever builder the scene builder is set to.
+int add_mesh_by_method(rt_scene_builder* b, std::vector<rt_vertex> v, std::vector<rt_tri> f,
+                       const rt_affine3a* transforms, size_t n_transforms, const BvhBuildParams& params) {
+    if (b->bvh_method == RT_BVH_HOST) {
+        b->sb.add_mesh(std::move(v), std::move(f), transforms, n_transforms, params);
+        return RT_OK;
+    }
+    // the reference's rule for the root: a mesh of up to root_leaf_max triangles stays one leaf (bvh.rs:17)
+    const uint32_t leaf_max = f.size() <= params.root_leaf_max ? (uint32_t)f.size() : params.leaf_max;
+    size_t n_nodes = 2 * f.size();
+    std::vector<rt_bvh> nodes(n_nodes);
+    const int rc = b->bvh_method == RT_BVH_DEVICE_LINEAR
+                       ? rt_create_bvh_device(b->bvh_device, v.data(), v.size(), f.data(), f.size(), leaf_max, nodes.data(), &n_nodes)
+                       : rt_create_bvh_device_sah(b->bvh_device, v.data(), v.size(), f.data(), f.size(), leaf_max,
+                                                  params.max_depth + 1u, nodes.data(), &n_nodes);
+    if (rc != RT_OK) return rc;
+    nodes.resize(n_nodes);
+    b->sb.add_built_mesh(v, f, nodes, transforms, n_transforms);
+    return RT_OK;
+}
 
 BvhBuildParams to_params(const rt_bvh_params* p) {
     BvhBuildParams out;
@@ -85,7 +109,14 @@ int rt_scene_builder_add_obj(rt_scene_builder* b, const char* text, size_t len, 
     std::vector<rt_tri> f;
     parse_obj(text, len, v, f);
     if (f.empty() || !mesh_is_buildable(v.data(), v.size(), f.data(), f.size())) return RT_ERR_INVALID;
-    b->sb.add_mesh(std::move(v), std::move(f), transforms, n_transforms, to_params(params));
+    return add_mesh_by_method(b, std::move(v), std::move(f), transforms, n_transforms, to_params(params));
+}
+
+int rt_scene_builder_use_bvh_builder(rt_scene_builder* b, int method, int device) {
+    if (!b || method < RT_BVH_HOST || method > RT_BVH_DEVICE_SAH) return RT_ERR_INVALID;
+    if (method != RT_BVH_HOST && device < 0) return RT_ERR_INVALID;
+    b->bvh_method = method;
+    b->bvh_device = method == RT_BVH_HOST ? -1 : device;
     return RT_OK;
 }
 
@@ -96,8 +127,7 @@ int rt_scene_builder_add_mesh(rt_scene_builder* b, const rt_vertex* vertices, si
     if (!mesh_is_buildable(vertices, n_vertices, triangles, n_triangles)) return RT_ERR_INVALID;
     std::vector<rt_vertex> v(vertices, vertices + n_vertices);
     std::vector<rt_tri> f(triangles, triangles + n_triangles);
-    b->sb.add_mesh(std::move(v), std::move(f), transforms, n_transforms, to_params(params));
-    return RT_OK;
+    return add_mesh_by_method(b, std::move(v), std::move(f), transforms, n_transforms, to_params(params));
 }
 
 int rt_scene_builder_add_built_mesh(rt_scene_builder* b, const rt_vertex* vertices, size_t n_vertices,

@@ -146,10 +146,17 @@ class SceneBuilder:
         arr = (L.Affine3A * len(transforms))(*transforms)
         return arr, len(transforms)
 
-    def add_obj_file(self, text, transforms, params=None):
+    _METHODS = {"host": L.RT_BVH_HOST, "gpu_linear": L.RT_BVH_DEVICE_LINEAR, "gpu_sah": L.RT_BVH_DEVICE_SAH}
+
+    def _use(self, builder):
+        if self._lib.rt_scene_builder_use_bvh_builder(self._b, self._METHODS[builder], 0) != L.RT_OK:
+            raise L.RtError(L.RT_ERR_INVALID, "rt_scene_builder_use_bvh_builder")
+
+    def add_obj_file(self, text, transforms, params=None, builder="host"):
         data = text.encode() if isinstance(text, str) else bytes(text)
         arr, n = self._xforms(transforms)
         p = params or bvh_params()
+        self._use(builder)
         rc = self._lib.rt_scene_builder_add_obj(self._b, data, len(data), arr, n, C.byref(p))
         if rc != L.RT_OK:
             raise L.RtError(rc, "rt_scene_builder_add_obj: unusable OBJ text")
@@ -164,14 +171,7 @@ class SceneBuilder:
         t = np.ascontiguousarray(triangles, np.uint32)
         arr, n = self._xforms(transforms)
         p = params or bvh_params()
-        if builder != "host":
-            method = {"gpu_sah": "sah", "gpu_linear": "linear"}[builder]
-            t, nodes = create_bvh_gpu(positions, t, leaf_max=int(p.leaf_max), method=method)
-            rc = self._lib.rt_scene_builder_add_built_mesh(self._b, _ptr(v), len(v), _ptr(t), len(t), _ptr(nodes),
-                                                           len(nodes), arr, n)
-            if rc != L.RT_OK:
-                raise L.RtError(rc, "rt_scene_builder_add_built_mesh: bad mesh or tree")
-            return self
+        self._use(builder)
         rc = self._lib.rt_scene_builder_add_mesh(self._b, _ptr(v), len(v), _ptr(t), len(t), arr, n, C.byref(p))
         if rc != L.RT_OK:
             raise L.RtError(rc, "rt_scene_builder_add_mesh: bad mesh")

@@ -347,8 +347,11 @@ def test_gpu_built_sah_bvh_is_a_valid_tree_and_renders_like_the_oracle(leaf_max)
     need = int(np.ceil(np.log2(np.ceil(len(faces) / leaf_max)))) + 1
     tight_t, tight_n = S.create_bvh_gpu(verts, faces, leaf_max=leaf_max, method="sah", max_levels=need)
     assert check_tree_vectorised(tight_n, tight_t, pos, leaf_max) == need
-    with pytest.raises(L.RtError):
-        S.create_bvh_gpu(verts, faces, leaf_max=leaf_max, method="sah", max_levels=need - 1)
+    # one level too few: the last level's nodes stay leaves whatever they hold (bvh.rs:75, 85)
+    short_t, short_n = S.create_bvh_gpu(verts, faces, leaf_max=leaf_max, method="sah", max_levels=need - 1)
+    assert check_tree_vectorised(short_n, short_t, pos, 2 * leaf_max) == need - 1
+    leaves = short_n[short_n["mode"] == 1]
+    assert (leaves["c2"] - leaves["c1"] + 1).max() > leaf_max
 
 
 def test_gpu_built_sah_bvh_of_a_million_triangles_is_exact_everywhere():

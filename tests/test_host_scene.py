@@ -337,6 +337,10 @@ def test_a_ready_made_tree_goes_into_a_scene_like_one_built_in_place():
     bad["c2"][0] = len(nodes) if bad["mode"][0] == 0 else len(ordered)
     assert lib.rt_scene_builder_add_built_mesh(b._b, S._ptr(vv), len(vv), S._ptr(ordered), len(ordered), S._ptr(bad),
                                                len(bad), xf, 2) == L.RT_ERR_INVALID
+    # which builder a scene builder uses: bad arguments are refused, the host builder needs no device
+    assert lib.rt_scene_builder_use_bvh_builder(b._b, 3, 0) == L.RT_ERR_INVALID
+    assert lib.rt_scene_builder_use_bvh_builder(b._b, L.RT_BVH_DEVICE_SAH, -1) == L.RT_ERR_INVALID
+    assert lib.rt_scene_builder_use_bvh_builder(b._b, L.RT_BVH_HOST, -1) == L.RT_OK
     n = C.c_size_t(0)
     tt = np.array([[0, 1, 9999]], np.uint32)
     assert lib.rt_create_bvh_device_sah(0, S._ptr(vv), len(vv), S._ptr(tt), 1, 4, 0, None, C.byref(n)) == L.RT_ERR_INVALID
