@@ -6,7 +6,10 @@
 Default workload = the configuration the Mrays/s metric and its 1/2/4/8-GPU
 figures are quoted on ("c3"): a seeded ~1.0 M-triangle procedural scene at
 1920x1080, 16 accumulated one-sample frames per step, depth 10, scene resident
-in HBM before the timed region.  With N > 1 (launched by torch.distributed.run,
+in HBM before the timed region.  The terrain's BVH comes from the library's own
+binned surface-area builder on the GPU (--builder gpu_sah, the default); the line
+also carries the same job on the tree of the reference's split rule built on the
+host (`reference_rule_tree`; --builder host makes that the headline).  With N > 1 (launched by torch.distributed.run,
 one process per GPU) the canvas is dealt to the ranks in interleaved 8-row
 strips; there is no collective in the data path.  The job is the same for every
 N (1920x1080, 16 spp, the same scene): "strong" scaling.  That 19 ms job is
@@ -74,7 +77,7 @@ BUILDERS = {"host": "BVH by the reference's split rule",
             "gpu_linear": "linear BVH built on the GPU"}
 
 
-def build_scene(name, leaf_max, threads, grid, canvas=None, builder="host"):
+def build_scene(name, leaf_max, threads, grid, canvas=None, builder="host", device=0):
     from ray_tracing_amd import sphere_field_scene, terrain_scene
 
     w, h, frames, depth, _ = CONFIGS[name]
@@ -82,18 +85,18 @@ def build_scene(name, leaf_max, threads, grid, canvas=None, builder="host"):
         w, h = canvas
     if name == "c2":
         scene, cam = sphere_field_scene(w, h, n_spheres=10000, seed=1, subdivisions=2, depth=depth, threads=threads,
-                                        leaf_max=leaf_max, builder=builder)
+                                        leaf_max=leaf_max, builder=builder, device=device)
         what = "10000 tessellated spheres (icosphere, 320 triangles each), diffuse instance under the sky"
     elif name == "c3":
-        scene, cam = terrain_scene(w, h, n=grid, depth=depth, threads=threads, leaf_max=leaf_max, builder=builder)
+        scene, cam = terrain_scene(w, h, n=grid, depth=depth, threads=threads, leaf_max=leaf_max, builder=builder, device=device)
         what = "procedural terrain, 3 instances (glass / diffuse / emissive)"
     elif name == "c4":
         scene, cam = terrain_scene(w, h, n=2236 if grid == 700 else grid, depth=depth, threads=threads,
-                                   leaf_max=leaf_max, builder=builder)
+                                   leaf_max=leaf_max, builder=builder, device=device)
         what = "procedural terrain, 3 instances (glass / diffuse / emissive)"
     else:
         scene, cam = terrain_scene(w, h, n=grid, depth=depth, closed_box=True, light=False, threads=threads,
-                                   leaf_max=leaf_max, builder=builder)
+                                   leaf_max=leaf_max, builder=builder, device=device)
         what = "procedural terrain inside a closed box, diffuse only"
     workload = (f"{what}, {scene.n_triangles} triangles, {w}x{h}, {frames} spp per step, depth {depth}, "
                 f"{BUILDERS[builder]} with leaves of at most {leaf_max} triangles")
@@ -134,8 +137,9 @@ def main():
     ap.add_argument("--grid", type=int, default=700, help="terrain grid resolution (700 -> ~1.0 M triangles)")
     ap.add_argument("--leaf-max", type=int, default=4,
                     help="largest leaf the BVH builder leaves unsplit (the reference's builder: 16, bvh.rs:75)")
-    ap.add_argument("--builder", choices=sorted(BUILDERS), default="host",
-                    help="who builds the big mesh's BVH: the reference's rule on the host (default) or a GPU builder")
+    ap.add_argument("--builder", choices=sorted(BUILDERS), default="gpu_sah",
+                    help="who builds the big mesh's BVH: the library's binned surface-area builder on the GPU "
+                         "(default), its linear builder, or the reference's split rule on the host")
     ap.add_argument("--pipeline", type=int, default=1, help="kernel: 0 plain nested loops, 1 persistent state machine")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="strong",
                     help="N > 1, tile-partitioned configs: strong = the config's own canvas (default), "
@@ -182,7 +186,8 @@ def main():
     width, height = canvas_for(args.config, world, args.scaling)
     scaling = "weak" if (args.scaling == "weak" and partition == "tile") else "strong"
     threads = max(1, min(os.cpu_count() or 1, 16) // max(1, world))
-    scene, cam0, workload = build_scene(args.config, args.leaf_max, threads, args.grid, (width, height), args.builder)
+    scene, cam0, workload = build_scene(args.config, args.leaf_max, threads, args.grid, (width, height), args.builder,
+                                        device_index)
     n_inst = int(scene.info.num_instances)
 
     stream = torch.cuda.current_stream().cuda_stream
@@ -321,10 +326,12 @@ def main():
         extras["weak_scaling"] = {"canvas": [ww, wh], "Mrays_per_s": rays / dt / 1e6,
                                   "ms_per_step": dt / max(2, args.steps // 2) * 1e3}
 
-    if world == 1 and partition == "tile" and args.config == "c3" and args.builder == "host" and not args.no_extras:
-        # the same job on the tree the library's own GPU builder makes of the same mesh
+    if world == 1 and partition == "tile" and args.config == "c3" and args.builder != "gpu_linear" and not args.no_extras:
+        # the same job on the other tree of the same mesh: the reference's split rule on the host when the
+        # headline is on the GPU-built tree, and the other way round
+        other = "host" if args.builder == "gpu_sah" else "gpu_sah"
         t0 = time.perf_counter()
-        scene2, _, _ = build_scene(args.config, args.leaf_max, threads, args.grid, (width, height), "gpu_sah")
+        scene2, _, _ = build_scene(args.config, args.leaf_max, threads, args.grid, (width, height), other, device_index)
         build_s = time.perf_counter() - t0
         app2 = App.create(L.CamData.from_buffer_copy(cam0), scene2, device=device_index, stream=stream)
         app2.set_option(RT_OPT_PIPELINE, args.pipeline)
@@ -336,11 +343,11 @@ def main():
             dt, rays, ms = timed(5, one_step)
         finally:
             app = main_app
-        extras["gpu_built_tree"] = {"builder": BUILDERS["gpu_sah"], "Mrays_per_s": rays / dt / 1e6,
-                                    "ms_per_step": dt / 5 * 1e3, "kernel_ms": ms,
-                                    "scene_build_s": build_s,
-                                    "what": "same scene, camera and frames; terrain tree from rt_create_bvh_device_sah "
-                                            "(scene_build_s covers mesh generation, the build and scene assembly)"}
+        extras["reference_rule_tree" if other == "host" else "gpu_built_tree"] = {
+            "builder": BUILDERS[other], "Mrays_per_s": rays / dt / 1e6, "ms_per_step": dt / 5 * 1e3, "kernel_ms": ms,
+            "scene_build_s": build_s,
+            "what": "same scene, camera and frames, the terrain's tree from the other builder "
+                    "(scene_build_s covers mesh generation, the build and scene assembly)"}
         app2.destroy()
 
     def committed_profile():

@@ -132,9 +132,11 @@ def single_object_scene(positions, triangles, nodes, transforms):
 class SceneBuilder:
     """program/src/modules/mod.rs:38-134, backed by the library's C++ builder."""
 
-    def __init__(self):
+    def __init__(self, device=0):
+        """`device`: the GPU the GPU BVH builders run on, for meshes added with builder="gpu_..."."""
         self._lib = L.load()
         self._b = self._lib.rt_scene_builder_new()
+        self._device = device
 
     def __del__(self):
         if getattr(self, "_b", None):
@@ -149,7 +151,7 @@ class SceneBuilder:
     _METHODS = {"host": L.RT_BVH_HOST, "gpu_linear": L.RT_BVH_DEVICE_LINEAR, "gpu_sah": L.RT_BVH_DEVICE_SAH}
 
     def _use(self, builder):
-        if self._lib.rt_scene_builder_use_bvh_builder(self._b, self._METHODS[builder], 0) != L.RT_OK:
+        if self._lib.rt_scene_builder_use_bvh_builder(self._b, self._METHODS[builder], self._device) != L.RT_OK:
             raise L.RtError(L.RT_ERR_INVALID, "rt_scene_builder_use_bvh_builder")
 
     def add_obj_file(self, text, transforms, params=None, builder="host"):
@@ -392,26 +394,26 @@ def _small_glass_cube(scale, translation):
 
 
 def sphere_field_scene(width=1920, height=1080, n_spheres=10000, seed=1, subdivisions=2, depth=5, threads=8,
-                       rmin=0.3, rmax=1.0, leaf_max=16, builder="host"):
+                       rmin=0.3, rmax=1.0, leaf_max=16, builder="host", device=0):
     """10k tessellated spheres under the sky, all in instance 1 (the diffuse
     NormalMaterial); instance 0 is a small glass cube at the centre."""
     cv, cf, ct = _small_glass_cube(2.0, (0.0, 0.0, 0.0))
     sv, sf = sphere_field(n_spheres, seed, subdivisions, rmin=rmin, rmax=rmax)
     ident = affine_from_srt((1, 1, 1), (0, 0, 0, 1), (0, 0, 0))
-    scene = (SceneBuilder().add_mesh(cv, cf, [ct])
+    scene = (SceneBuilder(device).add_mesh(cv, cf, [ct])
              .add_mesh(sv, sf, [ident], bvh_params(leaf_max=leaf_max, threads=threads), builder=builder).build())
     cam = make_cam(width, height, affine_from_srt((1, 1, 1), (0, 0, 0, 1), (0.0, 0.0, -115.0)), depth=depth)
     return scene, cam
 
 
 def terrain_scene(width=1920, height=1080, n=700, seed=2, depth=10, closed_box=False, threads=8, light=True,
-                  leaf_max=16, builder="host"):
+                  leaf_max=16, builder="host", device=0):
     """~1M-triangle procedural terrain as instance 1 (diffuse), a glass cube as
     instance 0 and, with `light`, an emissive sphere as instance 2."""
     cv, cf, ct = _small_glass_cube(6.0, (10.0, 22.0, 5.0))
     tv, tf = terrain(n=n, seed=seed, closed_box=closed_box)
     ident = affine_from_srt((1, 1, 1), (0, 0, 0, 1), (0, 0, 0))
-    b = SceneBuilder().add_mesh(cv, cf, [ct]).add_mesh(tv, tf, [ident], bvh_params(leaf_max=leaf_max, threads=threads),
+    b = SceneBuilder(device).add_mesh(cv, cf, [ct]).add_mesh(tv, tf, [ident], bvh_params(leaf_max=leaf_max, threads=threads),
                                                         builder=builder)
     if light:
         lv, lf = icosphere(2)

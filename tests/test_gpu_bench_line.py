@@ -35,5 +35,6 @@ def test_default_bench_line_has_the_contract_keys():
     assert c["kind"] == "port" and c["unit"] == "Mrays/s" and c["cores"] >= 1 and 0.0 < c["value"] < d["value"]
     assert d["ms_per_lone_frame"] > d["ms_per_frame"] > 0.0
     assert d["first_launch_of_a_view"]["kernel_ms"] > 0.0 and d["strong_scaling_floor"]["ms_per_step"] < d["ms_per_step"]
-    g = d["gpu_built_tree"]
-    assert g["Mrays_per_s"] > 1000.0
+    assert "binned surface-area splits on the GPU" in d["config"]["workload"]
+    g = d["reference_rule_tree"]  # the same job on the tree of the reference's own split rule
+    assert g["Mrays_per_s"] > 1000.0 and "reference's split rule" in g["builder"]
