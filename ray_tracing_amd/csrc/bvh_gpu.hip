@@ -25,6 +25,7 @@
 #include <vector>
 
 #include "../../include/rt_hip.h"
+#include "bvh_pad.hpp"
 #include "host_scene.hpp"
 
 namespace {
@@ -229,7 +230,9 @@ __global__ void emit_nodes(int n_leaves, uint32_t leaf_max, const uint32_t* left
     if (node >= (uint32_t)(2 * n_leaves - 1) || !keep[node]) return;
     uint32_t lo, hi;
     node_range(node, n_leaves, range_lo, range_hi, lo, hi);
-    rt_bvh o = full[node];  // the box
+    rt_bvh o = full[node];  // the box; widened where it has no thickness along an axis (bvh_pad.hpp)
+    const rt_bvh root = full[0];
+    rt::widen_flat_box(o.bounding_box.min, o.bounding_box.max, rt::flat_box_pad(root.bounding_box.min, root.bounding_box.max));
     if (hi - lo + 1u <= leaf_max) {
         o.child_1_or_first_tri = lo;
         o.child_2_or_last_tri = hi;

@@ -22,7 +22,9 @@
 //               so the same input always gives the same array of nodes.
 // A node whose centroids all fall into one bin on every axis (coincident centroids), or whose
 // cheapest split would leave a side too big for the levels that remain, is cut in the middle of
-// its range instead; its children's boxes are then gathered by the scatter pass.
+// its range instead; its children's boxes are then gathered by the scatter pass.  Boxes without
+// thickness along an axis, which the reference's slab test never accepts, are widened a little at
+// the end (bvh_pad.hpp).
 #include <hip/hip_runtime.h>
 
 #include <hipcub/hipcub.hpp>
@@ -32,6 +34,7 @@
 #include <utility>
 
 #include "../../include/rt_hip.h"
+#include "bvh_pad.hpp"
 #include "host_scene.hpp"
 
 namespace {
@@ -389,6 +392,12 @@ __global__ void scatter_kernel(uint32_t n, const uint32_t* ids, const uint32_t* 
     }
 }
 
+// Last pass over the finished nodes: boxes with (next to) no thickness along an axis are widened (bvh_pad.hpp).
+__global__ void widen_flat_boxes_kernel(rt_bvh* nodes, uint32_t n_nodes, float pad) {
+    const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
+    if (i < n_nodes) rt::widen_flat_box(nodes[i].bounding_box.min, nodes[i].bounding_box.max, pad);
+}
+
 __global__ void gather_triangles_kernel(const rt_tri* in, const uint32_t* ids, uint32_t n, rt_tri* out) {
     const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
     if (i < n) out[i] = in[ids[i]];
@@ -541,6 +550,8 @@ extern "C" int rt_create_bvh_device_sah(int device, const rt_vertex* vertices, s
         cur ^= 1;
     }
     if (*n_nodes < n_nodes_out) return RT_ERR_INVALID;
+    hipLaunchKernelGGL(widen_flat_boxes_kernel, grid_for(n_nodes_out), dim3(kThreads), 0, 0, d_nodes.p, n_nodes_out,
+                       rt::flat_box_pad(rb.lo, rb.hi));
     hipLaunchKernelGGL(gather_triangles_kernel, grid_for(n), dim3(kThreads), 0, 0, d_t.p, d_ids[cur].p, n, d_sorted.p);
     RT_TRY(hipGetLastError());
     RT_TRY(hipDeviceSynchronize());

@@ -214,8 +214,27 @@ def test_leaves_with_more_triangles_than_a_wave_has_lanes():
         assert (ref.hit_triangle != 0xFFFFFFFF).mean() > 0.1
 
 
-def check_tree(nodes, n_triangles, leaf_max):
-    """Every triangle in exactly one leaf, every node reachable once, boxes nested."""
+def flat_pad(pos):
+    """What the GPU builders widen boxes without thickness by: 2^-16 of the mesh's largest extent
+    (bvh_pad.hpp), in float32 like the builders."""
+    lo, hi = pos.min(0).astype(F), pos.max(0).astype(F)
+    ext, mag = F((hi - lo).max()), F(max(np.abs(lo).max(), np.abs(hi).max()))
+    scale = ext if ext > 0 else (mag if mag > 0 else F(1.0))
+    return F(scale * F(2.0 ** -16))
+
+
+def widened(lo, hi, pad):
+    """Boxes (n, 3) with every axis thinner than `pad` widened by it on both sides."""
+    lo, hi = lo.astype(F).copy(), hi.astype(F).copy()
+    thin = (hi - lo) < pad
+    lo[thin] = (lo[thin] - pad).astype(F)
+    hi[thin] = (hi[thin] + pad).astype(F)
+    return lo, hi
+
+
+def check_tree(nodes, n_triangles, leaf_max, pad=0.0):
+    """Every triangle in exactly one leaf, every node reachable once, boxes nested (a widened flat
+    child may stick out of its parent by the widening)."""
     seen_tri = np.zeros(n_triangles, np.int32)
     seen_node = np.zeros(len(nodes), np.int32)
     stack = [(0, None)]
@@ -224,7 +243,7 @@ def check_tree(nodes, n_triangles, leaf_max):
         seen_node[i] += 1
         nd = nodes[i]
         if parent_box is not None:
-            assert (nd["min"] >= parent_box[0]).all() and (nd["max"] <= parent_box[1]).all()
+            assert (nd["min"] >= parent_box[0] - pad).all() and (nd["max"] <= parent_box[1] + pad).all()
         if nd["mode"] == 1:
             assert nd["c1"] <= nd["c2"] < n_triangles and nd["c2"] - nd["c1"] < leaf_max
             seen_tri[nd["c1"]:nd["c2"] + 1] += 1
@@ -243,12 +262,9 @@ def test_gpu_built_linear_bvh_is_a_valid_tree_and_renders_like_the_oracle(leaf_m
     tris, nodes = S.create_bvh_gpu(verts, faces, leaf_max=leaf_max)
     assert sorted(map(tuple, tris.tolist())) == sorted(map(tuple, faces.tolist()))
     assert 2 * ((len(faces) + leaf_max - 1) // leaf_max) - 1 <= len(nodes) <= 2 * len(faces) - 1
-    check_tree(nodes, len(tris), leaf_max)
-    # leaf boxes hold their triangles
     pos = np.asarray(verts, F)
-    for nd in nodes[nodes["mode"] == 1][:200]:
-        p = pos[tris[nd["c1"]:nd["c2"] + 1].ravel()]
-        assert (p.min(0) == nd["min"]).all() and (p.max(0) == nd["max"]).all()
+    check_tree(nodes, len(tris), leaf_max, flat_pad(pos))
+    check_tree_vectorised(nodes, tris, pos, leaf_max)  # every box: the bounds of its triangles
     ident = S.affine_from_srt((1, 1, 1), (0, 0, 0, 1), (0, 0, 0))
     shifted = S.affine_from_srt((0.5, 0.5, 0.5), S.quat_from_rotation("y", 0.7), (10, 25, 0))
     scene = S.single_object_scene(pos, tris, nodes, [ident, shifted])
@@ -265,8 +281,8 @@ def test_gpu_built_linear_bvh_is_a_valid_tree_and_renders_like_the_oracle(leaf_m
 
 def check_tree_vectorised(nodes, tris, pos, leaf_max):
     """check_tree for trees too large to walk node by node in Python, and stricter: every node
-    reached exactly once from the root, leaves tile the triangle array, every leaf box is exactly
-    the bounds of its triangles and every internal box exactly the union of its children's."""
+    reached exactly once from the root, leaves tile the triangle array, every box is exactly the
+    bounds of the triangles below it (widened by the builders' rule where those are flat)."""
     n_nodes, n_tris = len(nodes), len(tris)
     internal = nodes["mode"] == 0
     c1, c2 = nodes["c1"].astype(np.int64), nodes["c2"].astype(np.int64)
@@ -274,10 +290,11 @@ def check_tree_vectorised(nodes, tris, pos, leaf_max):
     assert kids.min() >= 1 and kids.max() < n_nodes
     refs = np.bincount(kids, minlength=n_nodes)
     assert refs[0] == 0 and (refs[1:] == 1).all(), "a node with no parent or with two"
-    seen, frontier, depth = np.zeros(n_nodes, bool), np.array([0]), 0
+    seen, frontier, depth, levels = np.zeros(n_nodes, bool), np.array([0]), 0, []
     while len(frontier):
         assert not seen[frontier].any()
         seen[frontier] = True
+        levels.append(frontier)
         inner = frontier[internal[frontier]]
         frontier = np.concatenate([c1[inner], c2[inner]])
         depth += 1
@@ -288,13 +305,20 @@ def check_tree_vectorised(nodes, tris, pos, leaf_max):
     first, last = c1[leaves][order], c2[leaves][order]
     assert first[0] == 0 and last[-1] == n_tris - 1 and (first[1:] == last[:-1] + 1).all(), "leaves do not tile the triangles"
     assert ((last - first) < leaf_max).all() and (last >= first).all()
+    # every box is exactly the bounds of the triangles below it, widened where those bounds have no
+    # thickness along an axis
     corners = pos[tris.ravel()].reshape(n_tris, 3, 3)
     tmin, tmax = corners.min(1), corners.max(1)
-    assert (np.minimum.reduceat(tmin, first) == nodes["min"][leaves][order]).all(), "a leaf box is not tight"
-    assert (np.maximum.reduceat(tmax, first) == nodes["max"][leaves][order]).all(), "a leaf box is not tight"
-    a, b = c1[internal], c2[internal]
-    assert (np.minimum(nodes["min"][a], nodes["min"][b]) == nodes["min"][internal]).all(), "an internal box is not the union"
-    assert (np.maximum(nodes["max"][a], nodes["max"][b]) == nodes["max"][internal]).all(), "an internal box is not the union"
+    tight_lo, tight_hi = np.zeros((n_nodes, 3), F), np.zeros((n_nodes, 3), F)
+    tight_lo[leaves[order]] = np.minimum.reduceat(tmin, first)
+    tight_hi[leaves[order]] = np.maximum.reduceat(tmax, first)
+    for level_nodes in reversed(levels):  # children before parents
+        inner = level_nodes[internal[level_nodes]]
+        tight_lo[inner] = np.minimum(tight_lo[c1[inner]], tight_lo[c2[inner]])
+        tight_hi[inner] = np.maximum(tight_hi[c1[inner]], tight_hi[c2[inner]])
+    want_lo, want_hi = widened(tight_lo, tight_hi, flat_pad(pos[tris.ravel()]))  # the pad follows the vertices in use
+    assert (want_lo == nodes["min"]).all(), "a box is not the (widened) bounds of its triangles"
+    assert (want_hi == nodes["max"]).all(), "a box is not the (widened) bounds of its triangles"
     return depth
 
 
@@ -326,7 +350,7 @@ def test_gpu_built_sah_bvh_is_a_valid_tree_and_renders_like_the_oracle(leaf_max)
     pos = np.asarray(verts, F)
     tris, nodes = S.create_bvh_gpu(verts, faces, leaf_max=leaf_max, method="sah")
     assert sorted(map(tuple, tris.tolist())) == sorted(map(tuple, faces.tolist()))
-    check_tree(nodes, len(tris), leaf_max)
+    check_tree(nodes, len(tris), leaf_max, flat_pad(pos))
     assert check_tree_vectorised(nodes, tris, pos, leaf_max) <= 33
     tris2, nodes2 = S.create_bvh_gpu(verts, faces, leaf_max=leaf_max, method="sah")
     assert tris2.tobytes() == tris.tobytes() and nodes2.tobytes() == nodes.tobytes()
@@ -668,3 +692,28 @@ def test_present_begin_end_hands_out_the_frame_it_was_started_for():
         app.present_begin()  # frame 3 before frame 2 was asked for: waits for that copy, then replaces it
         assert np.array_equal(app.present_end(), frames[2])
         assert np.array_equal(app.read_present_rgba8(), frames[2])
+
+
+@pytest.mark.parametrize("builder", ["gpu_sah", "gpu_linear"])
+def test_gpu_builders_keep_axis_aligned_walls_visible(builder):
+    """The reference's slab test never accepts a box without thickness (trace.rs:208-229), and a
+    builder that splits by surface area puts an axis-aligned wall into leaves of its own, whose
+    tight boxes are exactly that.  The GPU builders widen such boxes a little; inside a closed
+    box every primary ray must then hit something, at the distance it does on the tree of the
+    reference's split rule, and the kernels must still agree with the oracle."""
+    verts, faces = S.terrain(n=60, closed_box=True)
+    pos, faces = np.asarray(verts, F), np.asarray(faces, np.uint32)
+    ident = S.affine_from_srt((1, 1, 1), (0, 0, 0, 1), (0, 0, 0))
+    cam = S.make_cam(160, 90, S.look_at((0.0, 55.0, -95.0), (0.0, 0.0, 0.0)), depth=4)
+    hits = {}
+    for b in ("host", builder):
+        scene = S.SceneBuilder().add_mesh(pos, faces, [ident], S.bvh_params(leaf_max=4), builder=b).build()
+        g, ref = check_against_oracle(scene, cam, frames=2)
+        assert (ref.hit_triangle != 0xFFFFFFFF).all(), f"{b}: a primary ray left the closed box"
+        hits[b] = ref.hit_t_bits.copy()
+    # the same surfaces at the same distances, whatever the tree (ties aside: none between a wall and the terrain)
+    assert (hits["host"] == hits[builder]).mean() > 0.999
+    tris, nodes = S.create_bvh_gpu(pos, faces, leaf_max=4, method="sah" if builder == "gpu_sah" else "linear")
+    check_tree_vectorised(nodes, tris, pos, 4)
+    thin = ((nodes["max"] - nodes["min"]) < 2 * flat_pad(pos) * F(1.01)).any(1)
+    assert thin.any() and ((nodes["max"] - nodes["min"])[thin].min() > 0)  # there were flat boxes, none is left flat
