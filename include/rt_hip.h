@@ -237,7 +237,12 @@ int rt_create_bvh(const rt_vertex* vertices, size_t n_vertices, rt_tri* triangle
  * reference's shader, or checked by the oracle like any other; it is NOT the tree
  * bvh.rs would build.  Leaves are the subtrees of at most `leaf_max` triangles; with
  * NULL `nodes` the count returned is an upper bound (2 n - 1), the second call returns
- * the actual one.  A tree deeper than rt_upload_scene accepts is only found out there. */
+ * the actual one.  A tree deeper than rt_upload_scene accepts is only found out there.
+ * Boxes are the exact bounds of their triangles with one exception, shared with
+ * rt_create_bvh_device_sah: a box thinner than 2^-16 of the mesh's largest extent along an
+ * axis is widened by that much on both sides of the axis, because the reference's slab
+ * test (trace.rs:225, t_near < t_far) never accepts a box without thickness and an
+ * axis-aligned wall in a node of its own would be invisible. */
 int rt_create_bvh_device(int device, const rt_vertex* vertices, size_t n_vertices, rt_tri* triangles,
                          size_t n_triangles, uint32_t leaf_max, rt_bvh* nodes, size_t* n_nodes);
 
