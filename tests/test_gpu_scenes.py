@@ -556,6 +556,55 @@ def test_full_size_rows_match_the_oracle(c3):
     assert_bits_equal(g["acc"][rows], ref.acc[rows], "accumulator")
 
 
+def compare_everything(g, ref):
+    tri, inst, tb = g["hits"]
+    assert_bits_equal(tri, ref.hit_triangle, "triangle_id")
+    assert_bits_equal(inst, ref.hit_instance, "instance_id")
+    assert_bits_equal(tb, ref.hit_t_bits, "t bits")
+    assert_bits_equal(g["counters"][0], ref.box_tests, "box_tests")
+    assert_bits_equal(g["counters"][1], ref.triangle_tests, "triangle_tests")
+    assert_bits_equal(g["acc"], ref.acc, "accumulator")
+    assert g["stats"] == ref.stats_dict()
+
+
+def test_whole_canvas_of_one_rank_of_config_4_matches_the_oracle():
+    """Config 4 at its full size: 10.0 M triangles (tree from the binned GPU builder), 3840x2160,
+    sample-split -- rank 5 of 8 renders frames 5 and 13 with the independent-seed variant; every
+    pixel of its accumulator, hit records and counters against the oracle in the same mode."""
+    scene, cam = terrain_scene(3840, 2160, n=2236, depth=10, leaf_max=4, builder="gpu_sah", device=0)
+    assert scene.n_triangles > 9_900_000
+    cam.frame = 5
+    g = gpu_render(scene, cam, 2, options=((RT_OPT_FRAME_STRIDE, 8), (RT_OPT_SEED_MODE, 1)))
+    ref = O.OracleRenderer(scene, copy_cam(cam), trig=O.TRIG_DET, threads=16, frame_stride=8, independent_seeds=True).render(2)
+    compare_everything(g, ref)
+    assert g["stats"]["paths"] == 2 * 3840 * 2160
+
+
+@pytest.mark.parametrize("config", ["c3", "c2", "c5"])
+def test_whole_canvas_of_the_bench_scenes_matches_the_oracle(config):
+    """The scenes bench.py times, at their full size and on the trees of its default builder (the
+    binned GPU builder), every pixel against the oracle -- hit records, counters, accumulator and
+    totals, not a band of rows.  c3: one whole bench step (1.0 M triangles, 1920x1080, 16 chained
+    frames, depth 10); c2: 10 000 tessellated spheres (3.2 M triangles), 1 frame, depth 5; c5: the
+    terrain in a closed box, all diffuse, depth 9, 4 frames."""
+    if config == "c3":
+        scene, cam = terrain_scene(1920, 1080, n=700, depth=10, leaf_max=4, builder="gpu_sah", device=0)
+        frames = 16
+    elif config == "c2":
+        scene, cam = sphere_field_scene(1920, 1080, n_spheres=10000, depth=5, leaf_max=4, builder="gpu_sah", device=0)
+        frames = 1
+    else:
+        scene, cam = terrain_scene(1920, 1080, n=700, depth=9, closed_box=True, light=False, leaf_max=4,
+                                   builder="gpu_sah", device=0)
+        frames = 4
+    g = gpu_render(scene, cam, frames)
+    ref = O.OracleRenderer(scene, cam, trig=O.TRIG_DET, threads=16).render(frames)
+    compare_everything(g, ref)
+    assert g["stats"]["paths"] == frames * 1920 * 1080
+    if config == "c5":  # nothing leaves the box and nothing in it emits: every path runs to the depth limit
+        assert g["stats"]["rays"] == 9 * g["stats"]["paths"]
+
+
 def test_full_size_properties(c3):
     """Size-independent properties at the benchmark size: both kernels agree, a
     render is reproducible, the 8-way strip partition reassembles to the same image,
