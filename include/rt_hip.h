@@ -15,7 +15,9 @@
  * thread-safe (the reference drives its App from the single winit thread);
  * different contexts may be driven from different host threads or processes.
  * Nothing here falls back to the CPU: without a usable HIP device rt_create
- * fails.
+ * fails.  Every call that works on a GPU (a context's, or the `device` argument
+ * of the builders and probes) makes that GPU the calling thread's current HIP
+ * device and leaves it current.
  */
 #ifndef RT_HIP_H
 #define RT_HIP_H
@@ -47,12 +49,15 @@ typedef struct rt_stats {
 } rt_stats;
 
 enum {
-    /* Which kernel renders.  Both compute the same bits.
+    /* Which kernel renders.  All compute the same bits.
      * 0 = plain: one lane per pixel runs nested frame / segment / instance /
      *     traversal loops, the shape of the reference's shader::main;
      * 1 = persistent (default): per-lane state machine (generate, extend,
      *     shade, accumulate as steps), wave-wide vote on the kind of step to
-     *     run, lanes refilled from per-XCD work queues. */
+     *     run, lanes refilled from per-XCD work queues;
+     * 2 = pooled: the persistent kernel with a pool of ray slots per wave, lanes
+     *     only traverse and paths are shaded 64 at a time (slower on every
+     *     workload measured; kept as the measured alternative). */
     RT_OPT_PIPELINE = 1,
     /* 1 = also record, for the FIRST segment of every path, the HitRecord
      *     (triangle_id, instance_id, t bits) -> rt_read_hits. */
@@ -114,13 +119,13 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene_info* info,
                     const rt_object* objects, size_t n_objects,
                     const rt_instance* instances, size_t n_instances,
                     const rt_bvh* bvh, size_t n_bvh);
-/* Per-instance materials (extension, see rt_abi.h).  n must equal the number
- * of instances.  NULL / 0 restores the reference's constants. */
 /* New transforms (and object ids) for the instances of the uploaded scene: what the reference
  * gets from refilling its instance buffer before every frame (vulkan.rs:238-353), at the cost of
  * one small copy instead of a scene upload.  n must equal the uploaded instance count; materials
  * stay as they are.  Waits for frames in flight on the context's stream. */
 int rt_update_instances(rt_ctx* ctx, const rt_instance* instances, size_t n);
+/* Per-instance materials (extension, see rt_abi.h).  n must equal the number
+ * of instances.  NULL / 0 restores the reference's constants. */
 int rt_set_materials(rt_ctx* ctx, const rt_material* materials, size_t n);
 void rt_default_material(uint32_t instance_id, rt_material* out);
 
