@@ -374,7 +374,9 @@ enum {
     RT_VALU_MIX_SHIFT_CVT = 14,  /* v_lshlrev_b32, v_cvt_f32_u32 */
     RT_VALU_MIX_MUL_LO = 15,     /* v_mul_lo_u32 */
     RT_VALU_MIX_DPP = 16,        /* v_add_u32 with a DPP row shift (the wave scans) */
-    RT_VALU_MIX_COUNT = 17
+    RT_VALU_MIX_BFI = 17,        /* v_bfi_b32: a bitwise select, three vector operands */
+    RT_VALU_MIX_AND_OR = 18,     /* v_and_or_b32 */
+    RT_VALU_MIX_COUNT = 19
 };
 typedef struct rt_valu_probe {
     uint64_t valu_insts;        /* vector instructions all waves issued inside their timed windows */

@@ -141,6 +141,16 @@ __device__ __forceinline__ void probe_body(float (&r)[16], pf2 (&p)[8], float a,
 #pragma unroll
             for (int k = 0; k < 16; ++k)
                 asm volatile("v_add_u32_dpp %0, %1, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(r[k]) : "v"(r[(k + 1) & 15]));
+    } else if constexpr (MIX == RT_VALU_MIX_BFI) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) asm volatile("v_bfi_b32 %0, %1, %0, %2" : "+v"(r[k]) : "v"(a), "v"(b));
+    } else if constexpr (MIX == RT_VALU_MIX_AND_OR) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) RT_P2("v_and_or_b32", k);
     } else {
         // The BOX step's proportions: of 64 instructions 24 packed multiply / add, 12 min / max,
         // 8 compares into scalar masks, 12 selects, 8 integer operations.
@@ -276,6 +286,8 @@ extern "C" int rt_probe_valu_issue(int device, int mix, uint32_t waves_per_simd,
             RT_CASE(RT_VALU_MIX_SHIFT_CVT);
             RT_CASE(RT_VALU_MIX_MUL_LO);
             RT_CASE(RT_VALU_MIX_DPP);
+            RT_CASE(RT_VALU_MIX_BFI);
+            RT_CASE(RT_VALU_MIX_AND_OR);
 #undef RT_CASE
         }
         if (e != hipSuccess || hipEventRecord(e1, 0) != hipSuccess || hipEventSynchronize(e1) != hipSuccess) rc = RT_ERR_HIP;
