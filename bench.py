@@ -9,7 +9,8 @@ figures are quoted on ("c3"): a seeded ~1.0 M-triangle procedural scene at
 in HBM before the timed region.  The terrain's BVH comes from the library's own
 binned surface-area builder on the GPU (--builder gpu_sah, the default); the line
 also carries the same job on the tree of the reference's split rule built on the
-host (`reference_rule_tree`; --builder host makes that the headline).  With N > 1 (launched by torch.distributed.run,
+host (`reference_rule_tree`; --builder host makes that the headline) and on the tree the reference's
+builder makes with its own leaf size of 16 (`reference_builder_tree`).  With N > 1 (launched by torch.distributed.run,
 one process per GPU) the canvas is dealt to the ranks in interleaved 8-row
 strips; there is no collective in the data path.  The job is the same for every
 N (1920x1080, 16 spp, the same scene): "strong" scaling.  That 19 ms job is
@@ -326,12 +327,11 @@ def main():
         extras["weak_scaling"] = {"canvas": [ww, wh], "Mrays_per_s": rays / dt / 1e6,
                                   "ms_per_step": dt / max(2, args.steps // 2) * 1e3}
 
-    if world == 1 and partition == "tile" and args.config == "c3" and args.builder != "gpu_linear" and not args.no_extras:
-        # the same job on the other tree of the same mesh: the reference's split rule on the host when the
-        # headline is on the GPU-built tree, and the other way round
-        other = "host" if args.builder == "gpu_sah" else "gpu_sah"
+    def same_job_on_another_tree(builder, leaf_max):
+        """The headline's scene, camera and frames with the terrain's tree from another builder."""
+        nonlocal app
         t0 = time.perf_counter()
-        scene2, _, _ = build_scene(args.config, args.leaf_max, threads, args.grid, (width, height), other, device_index)
+        scene2, _, _ = build_scene(args.config, leaf_max, threads, args.grid, (width, height), builder, device_index)
         build_s = time.perf_counter() - t0
         app2 = App.create(L.CamData.from_buffer_copy(cam0), scene2, device=device_index, stream=stream)
         app2.set_option(RT_OPT_PIPELINE, args.pipeline)
@@ -343,12 +343,20 @@ def main():
             dt, rays, ms = timed(5, one_step)
         finally:
             app = main_app
-        extras["reference_rule_tree" if other == "host" else "gpu_built_tree"] = {
-            "builder": BUILDERS[other], "Mrays_per_s": rays / dt / 1e6, "ms_per_step": dt / 5 * 1e3, "kernel_ms": ms,
-            "scene_build_s": build_s,
-            "what": "same scene, camera and frames, the terrain's tree from the other builder "
-                    "(scene_build_s covers mesh generation, the build and scene assembly)"}
-        app2.destroy()
+            app2.destroy()
+        return {"builder": f"{BUILDERS[builder]}, leaves of at most {leaf_max} triangles", "Mrays_per_s": rays / dt / 1e6,
+                "ms_per_step": dt / 5 * 1e3, "kernel_ms": ms, "scene_build_s": build_s,
+                "what": "same scene, camera and frames, the terrain's tree from another builder "
+                        "(scene_build_s covers mesh generation, the build and scene assembly)"}
+
+    if world == 1 and partition == "tile" and args.config == "c3" and args.builder != "gpu_linear" and not args.no_extras:
+        # the same job on the other tree of the same mesh: the reference's split rule on the host when the
+        # headline is on the GPU-built tree, and the other way round
+        other = "host" if args.builder == "gpu_sah" else "gpu_sah"
+        extras["reference_rule_tree" if other == "host" else "gpu_built_tree"] = same_job_on_another_tree(other, args.leaf_max)
+        if args.leaf_max != 16:
+            # and on the tree the reference's builder makes when left alone: its rule with its own leaf size (bvh.rs:75)
+            extras["reference_builder_tree"] = same_job_on_another_tree("host", 16)
 
     def committed_profile():
         """Per-launch hardware counters of this very workload from the committed rocprofv3 PMC

@@ -38,3 +38,5 @@ def test_default_bench_line_has_the_contract_keys():
     assert "binned surface-area splits on the GPU" in d["config"]["workload"]
     g = d["reference_rule_tree"]  # the same job on the tree of the reference's own split rule
     assert g["Mrays_per_s"] > 1000.0 and "reference's split rule" in g["builder"]
+    g16 = d["reference_builder_tree"]  # ... and with the reference builder's own leaf size
+    assert g16["Mrays_per_s"] > 1000.0 and "at most 16 triangles" in g16["builder"]
