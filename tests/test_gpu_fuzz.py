@@ -151,8 +151,9 @@ def test_random_scene_with_every_material_kind_matches_the_oracle(seed):
 @pytest.mark.parametrize("seed", range(int(os.environ.get("RT_FUZZ_EXTRA", "0"))))
 def test_extra_random_scenes_on_request(seed):
     """A soak run: RT_FUZZ_EXTRA=n adds n more scenes (all material kinds, every fourth one large,
-    the trees by the host builder and the two GPU builders in turn)."""
-    rng = np.random.default_rng(20000 + seed)
+    the trees by the host builder and the two GPU builders in turn); RT_FUZZ_BASE=m moves on to
+    scenes no earlier soak has seen."""
+    rng = np.random.default_rng(20000 + int(os.environ.get("RT_FUZZ_BASE", "0")) + seed)
     big = seed % 4 == 3
     builder = ("host", "gpu_sah", "gpu_linear")[(seed // 4) % 3]
     w, h = (int(rng.integers(40, 100)), int(rng.integers(30, 70))) if big else (int(rng.integers(5, 70)), int(rng.integers(5, 50)))
