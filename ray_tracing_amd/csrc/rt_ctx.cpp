@@ -297,8 +297,11 @@ int render(rt_ctx* c, const rt_cam_data& cam, uint32_t n_frames, const DevFrame*
 
     if (!own_buffers && (c->pipeline == 0 || !offsets_fit))
         return fail(c, RT_ERR_INVALID, "the no-allocation entry point runs the persistent kernel only");
+    // depth 0: Ray::get_color's loop runs zero times and every sample is black (trace.rs:193-205); the
+    // persistent kernels are built around "a path has a first segment", the plain one follows the loop
+    const bool plain = c->pipeline == 0 || !offsets_fit || cam.depth == 0;
     RT_HIP(c, hipEventRecord(c->ev0, c->stream));
-    if (c->pipeline == 0 || !offsets_fit) {
+    if (plain) {
         RT_HIP(c, launch_path_kernel(sc, dc, rows, fr, n_frames, stack_needed, count, c->stream));
     } else {
         const uint32_t n_tiles = persistent_tile_count(dc, rows);

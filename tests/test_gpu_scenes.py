@@ -70,6 +70,39 @@ def test_odd_canvas_sizes():
         check_against_oracle(scene, S.make_cam(w, h), frames=2)
 
 
+@pytest.mark.parametrize("pipeline", [0, 1, 2])
+def test_degenerate_depths_canvases_and_frame_counts(pipeline):
+    """Depth 0 (Ray::get_color's loop runs zero times: every sample is black and nothing is traced,
+    trace.rs:193-205), depth 1 and 2; canvases of one pixel, one row, one column; a call for zero
+    frames; extreme fields of view -- on every kernel, against the oracle."""
+    scene, cam = default_scene(32, 18)
+    for depth in (0, 1, 2):
+        c = copy_cam(cam)
+        c.depth = depth
+        g, ref = check_against_oracle(scene, c, frames=3, pipeline=pipeline)
+        if depth == 0:
+            assert g["stats"]["rays"] == 0 and g["stats"]["paths"] == 3 * 32 * 18
+            assert (g["acc"][..., :3] == 0.0).all() and (g["acc"][..., 3] == 3.0).all()
+            assert (g["hits"][0] == 0xFFFFFFFF).all()
+    for w, h in ((1, 1), (7, 1), (1, 9)):
+        check_against_oracle(scene, S.make_cam(w, h), frames=2, pipeline=pipeline)
+    g = gpu_render(scene, cam, 0, pipeline=pipeline)  # a call for no frames: a canvas, nothing on it
+    assert g["stats"]["paths"] == 0 and g["stats"]["rays"] == 0 and g["acc"].shape == (18, 32, 4) and (g["acc"] == 0.0).all()
+    for fov in (1.0, 179.0):
+        c = copy_cam(cam)
+        c.fov = fov
+        check_against_oracle(scene, c, frames=1, pipeline=pipeline)
+
+
+def test_a_scene_without_instances_is_refused():
+    scene, cam = default_scene(16, 9)
+    info = L.SceneInfo(0, scene.info.num_bvh_nodes, scene.info.num_triangles, scene.info.sun_orientation)
+    empty = S.Scene(info, scene.vertices, scene.triangles, scene.objects, scene.instances[:0].copy(), scene.bvh)
+    with pytest.raises(RtError) as e:
+        App.create(copy_cam(cam), empty)
+    assert e.value.code == L.RT_ERR_INVALID
+
+
 def test_material_table():
     """Per-instance materials (the reference hard-wires them, trace.rs:15-23): every
     branch of GenericMaterial::bxdf -- specular, refract/reflect, rough diffuse."""

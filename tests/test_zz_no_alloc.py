@@ -51,6 +51,18 @@ def test_noalloc_matches_render_frames_twice_second_smaller():
         assert_bits_equal(acc.cpu().numpy(), more[0], "accumulator after 5 + 3 frames")
         assert_bits_equal(shown.cpu().numpy(), want_b[1], "presented image must not have been touched")
 
+        # depth 0 (every sample black, nothing traced) takes the plain kernel: no allocation either
+        acc.zero_()
+        torch.cuda.synchronize()
+        app.cam_data = copy_cam(cam_b)
+        app.cam_data.depth = 0
+        free_before = torch.cuda.mem_get_info(0)[0]
+        app.render_frames_noalloc(2, acc.data_ptr(), None)
+        app.synchronize()
+        assert torch.cuda.mem_get_info(0)[0] == free_before
+        got = acc.cpu().numpy()
+        assert (got[..., :3] == 0.0).all() and (got[..., 3] == 2.0).all()
+
 
 def test_noalloc_limits():
     import torch
