@@ -136,6 +136,32 @@ def test_material_table():
         app.destroy()
 
 
+@pytest.mark.parametrize("pipeline", [0, 1, 2])
+def test_overbright_samples_trip_the_accumulator_guard(pipeline):
+    """shader/src/lib.rs:71-98: a sample with a channel above 1000 makes the accumulator
+    (0, 1e6, 0, 1) on every frame but the first after a move, which stores the sample as it is.
+    A light of (40000, 20, 20) behind the default scene's emissive instance trips it wherever a
+    path ends on the light; the rest of the image accumulates as usual."""
+    scene, cam = default_scene(160, 90)
+    table = []
+    for i in range(int(scene.info.num_instances)):
+        m = Material()
+        L.load().rt_default_material(i, C.byref(m))
+        table.append(m)
+    table[2].kind = RT_MAT_EMISSIVE
+    table[2].color[:] = (40000.0, 20.0, 20.0)
+    g, ref = check_against_oracle(scene, cam, frames=1, materials=table, pipeline=pipeline)
+    first = g["acc"]
+    assert (first[..., 0] > 1000.0).sum() > 50, "no path ends on the light: the test tests nothing"
+    assert not (first == np.array([0.0, 1.0e6, 0.0, 1.0], F)).all(-1).any()  # the first frame is stored as it is
+    g, ref = check_against_oracle(scene, cam, frames=4, materials=table, pipeline=pipeline)
+    tripped = (g["acc"] == np.array([0.0, 1.0e6, 0.0, 1.0], F)).all(-1)
+    assert tripped.sum() > 50 and not tripped.all()
+    shown = g["present"][tripped]  # (0, 1e6 / 4, 0) through the gamma curve
+    np.testing.assert_allclose(shown[:, 1], F(1.0e6 / 4.0) ** F(1.0 / 2.2), rtol=1e-5)
+    assert (shown[:, 0] == 0.0).all() and (shown[:, 2] == 0.0).all()
+
+
 # ------------------------------------------------------------ hand-built BVHs ------
 def ortho_like_cam(w, h, z=6.0, fov=60.0, depth=3):
     """Looks down -z onto the xy-plane from (0, 0, z)."""
