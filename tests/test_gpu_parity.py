@@ -89,3 +89,11 @@ def test_debug_heat_maps(c1, mode):
     ref = O.OracleRenderer(scene, cam, trig=O.TRIG_DET).render(1)
     assert_bits_equal(g["acc"], ref.acc, "heat map")
     assert (g["acc"][..., 0] == 1.0).any() and (g["acc"][..., 1] == 0.0).any()  # some saturated-red pixels
+    # the threshold at its extremes, over several frames, on every kernel: 0 divides 0 by 0 wherever
+    # nothing was tested (a NaN sample, which the accumulator keeps), 1 saturates nearly everything
+    for number in (0, 1, 100000):
+        cam.debug_number = number
+        for pipeline in (0, 1, 2):
+            g = gpu_render(scene, cam, 3, pipeline=pipeline)
+            ref = O.OracleRenderer(scene, cam, trig=O.TRIG_DET).render(3)
+            assert_bits_equal(g["acc"], ref.acc, f"heat map, threshold {number}, kernel {pipeline}", nan_equal=True)
