@@ -19,18 +19,17 @@ def case(name, scene, cam, frames=2):
         print(name, "RAISED", type(e).__name__, e, flush=True)
 
 scene, cam = S.default_scene(32, 18)
-for d in (0, 1, 2):
-    c = copy_cam(cam); c.depth = d
-    case(f"depth {d}", scene, c)
-for w, h in ((1, 1), (7, 1), (1, 9), (8, 8), (9, 9)):
-    s2, c2 = S.default_scene(w, h)
-    case(f"canvas {w}x{h}", s2, c2)
-case("0 frames", scene, cam, frames=0)
-# no instances at all
-info = L.SceneInfo(0, scene.info.num_bvh_nodes, scene.info.num_triangles, scene.info.sun_orientation)
-empty = S.Scene(info, scene.vertices, scene.triangles, scene.objects, scene.instances[:0].copy(), scene.bvh)
-case("no instances", empty, cam)
-c = copy_cam(cam); c.fov = 179.0
-case("fov 179", scene, c)
-c = copy_cam(cam); c.fov = 1.0
-case("fov 1", scene, c)
+c = copy_cam(cam); c.depth = 64
+case("depth 64", scene, c)
+c = copy_cam(cam); c.frame = 0xFFFFFFFE
+case("frame wrap", scene, c, frames=4)
+c = copy_cam(cam); c.frames_without_move = 3.0e7
+case("fwm 3e7", scene, c, frames=3)
+for w, h in ((0, 5), (5, 0)):
+    c = copy_cam(cam); c.canvas_width, c.canvas_height = w, h
+    case(f"canvas {w}x{h}", scene, c)
+# a singular instance transform (scale 0 along y)
+sing = S.affine_from_srt((1.0, 0.0, 1.0), (0, 0, 0, 1), (0, 0, 0))
+s3 = S.Scene(scene.info, scene.vertices, scene.triangles, scene.objects, scene.instances.copy(), scene.bvh)
+s3.instances["transform"][1] = np.frombuffer(bytes(sing), np.float32)
+case("singular transform", s3, cam)

@@ -94,6 +94,28 @@ def test_degenerate_depths_canvases_and_frame_counts(pipeline):
         check_against_oracle(scene, c, frames=1, pipeline=pipeline)
 
 
+def test_extreme_camera_fields_and_a_singular_instance():
+    """A depth well beyond the usual 10, a frame counter that wraps past 2^32 (the event loop's
+    `frame += 1`, main.rs:147), a frames_without_move so large that adding 1 no longer changes it,
+    and an instance whose transform has no inverse (its object-space rays are not finite and hit
+    nothing) -- against the oracle; a canvas without pixels is refused."""
+    scene, cam = default_scene(32, 18)
+    for field, value, frames in (("depth", 64, 2), ("frame", 0xFFFFFFFE, 4), ("frames_without_move", 3.0e7, 3)):
+        c = copy_cam(cam)
+        setattr(c, field, value)
+        check_against_oracle(scene, c, frames=frames)
+    flat = S.Scene(scene.info, scene.vertices, scene.triangles, scene.objects, scene.instances.copy(), scene.bvh)
+    flat.instances["transform"][1] = np.frombuffer(bytes(S.affine_from_srt((1.0, 0.0, 1.0), (0, 0, 0, 1), (0, 0, 0))), F)
+    for pipeline in (0, 1, 2):
+        check_against_oracle(flat, cam, frames=2, pipeline=pipeline, nan_equal=True)
+    for w, h in ((0, 5), (5, 0)):
+        c = copy_cam(cam)
+        c.canvas_width, c.canvas_height = w, h
+        with pytest.raises(RtError) as e:
+            gpu_render(scene, c, 1)
+        assert e.value.code == L.RT_ERR_INVALID
+
+
 def test_a_scene_without_instances_is_refused():
     scene, cam = default_scene(16, 9)
     info = L.SceneInfo(0, scene.info.num_bvh_nodes, scene.info.num_triangles, scene.info.sun_orientation)
