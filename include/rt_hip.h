@@ -230,7 +230,8 @@ int rt_parse_obj(const char* text, size_t len, rt_vertex* vertices, size_t* n_ve
                  rt_tri* triangles, size_t* n_triangles);
 /* bvh::create_bvh (bvh.rs:7-28): reorders `triangles` in place, writes up to
  * *n_nodes nodes (LOCAL indices) and returns the count in *n_nodes.  Pass
- * nodes == NULL to run the build and get only the count. */
+ * nodes == NULL to run the build and get only the count; that call, and a call
+ * refused because *n_nodes is too small, leave `triangles` as they were. */
 int rt_create_bvh(const rt_vertex* vertices, size_t n_vertices, rt_tri* triangles, size_t n_triangles,
                   const rt_bvh_params* params, rt_bvh* nodes, size_t* n_nodes);
 

@@ -39,11 +39,17 @@ float parse_f32(const char* s, size_t n) {
     return std::strtof(tmp.c_str(), nullptr);
 }
 
-int32_t parse_face_index(const char* s, size_t n) {
+// The index before the first '/', as the reference's parse::<i32> reads it.  Where the reference
+// panics (not a number, out of range) this yields an index that no mesh has, which the checks on
+// the finished mesh then refuse; the arithmetic on it is done in 64 bits so that nothing overflows.
+int64_t parse_face_index(const char* s, size_t n) {
     size_t k = 0;
     while (k < n && s[k] != '/') ++k;
     std::string tmp(s, k);
-    return int32_t(std::strtol(tmp.c_str(), nullptr, 10));
+    long long v = std::strtoll(tmp.c_str(), nullptr, 10);
+    if (v > INT32_MAX) v = INT32_MAX;
+    if (v < INT32_MIN) v = INT32_MIN;
+    return v;
 }
 
 }  // namespace
@@ -71,11 +77,11 @@ void parse_obj(const char* text, size_t len, std::vector<rt_vertex>& vertices, s
             // index is resolved against the number of tokens on the face
             // line, as the reference does (its inner `vertices` shadows the
             // vertex list, mod.rs:20, 25-27).
-            const int32_t n_face = int32_t(tok.t.size() - 1);
-            int32_t v1 = parse_face_index(tok.t[1].first, tok.t[1].second) - 1;
-            int32_t prev = parse_face_index(tok.t[2].first, tok.t[2].second) - 1;
+            const int64_t n_face = int64_t(tok.t.size() - 1);
+            int64_t v1 = parse_face_index(tok.t[1].first, tok.t[1].second) - 1;
+            int64_t prev = parse_face_index(tok.t[2].first, tok.t[2].second) - 1;
             for (size_t k = 3; k < tok.t.size(); ++k) {
-                int32_t v2 = parse_face_index(tok.t[k].first, tok.t[k].second) - 1;
+                int64_t v2 = parse_face_index(tok.t[k].first, tok.t[k].second) - 1;
                 rt_tri f;
                 f.i0 = v1 < 0 ? uint32_t(n_face + v1) : uint32_t(v1);
                 f.i1 = prev < 0 ? uint32_t(n_face + prev) : uint32_t(prev);

@@ -74,11 +74,11 @@ int rt_parse_obj(const char* text, size_t len, rt_vertex* vertices, size_t* n_ve
     parse_obj(text, len, v, f);
     if (vertices) {
         if (*n_vertices < v.size()) return RT_ERR_INVALID;
-        std::memcpy(vertices, v.data(), v.size() * sizeof(rt_vertex));
+        if (!v.empty()) std::memcpy(vertices, v.data(), v.size() * sizeof(rt_vertex));
     }
     if (triangles) {
         if (*n_triangles < f.size()) return RT_ERR_INVALID;
-        std::memcpy(triangles, f.data(), f.size() * sizeof(rt_tri));
+        if (!f.empty()) std::memcpy(triangles, f.data(), f.size() * sizeof(rt_tri));
     }
     *n_vertices = v.size();
     *n_triangles = f.size();
@@ -89,10 +89,15 @@ int rt_create_bvh(const rt_vertex* vertices, size_t n_vertices, rt_tri* triangle
                   const rt_bvh_params* params, rt_bvh* nodes, size_t* n_nodes) {
     if (!vertices || !triangles || !n_nodes || n_triangles == 0) return RT_ERR_INVALID;
     if (!mesh_is_buildable(vertices, n_vertices, triangles, n_triangles)) return RT_ERR_INVALID;
-    std::vector<rt_bvh> out = create_bvh(vertices, n_vertices, triangles, n_triangles, to_params(params));
+    // The build sorts a copy: the caller's triangles change only together with a tree handed out, so
+    // the counting call and a refused call leave them as they were (the order of equal centroids
+    // depends on the order coming in, and with it the tree and its size).
+    std::vector<rt_tri> sorted(triangles, triangles + n_triangles);
+    std::vector<rt_bvh> out = create_bvh(vertices, n_vertices, sorted.data(), n_triangles, to_params(params));
     if (nodes) {
         if (*n_nodes < out.size()) return RT_ERR_INVALID;
         std::memcpy(nodes, out.data(), out.size() * sizeof(rt_bvh));
+        std::memcpy(triangles, sorted.data(), n_triangles * sizeof(rt_tri));
     }
     *n_nodes = out.size();
     return RT_OK;
