@@ -1,0 +1,140 @@
+// Host-side fuzz of the scene check every upload goes through (build_gpu_scene, gpu_layout.cpp), built
+// with AddressSanitizer and UBSan: arbitrary scene buffers -- random links, cycles, shared children,
+// ranges that run off the end, non-finite boxes and transforms -- must be refused, or turned into a
+// device layout in which every index a kernel would follow is in range and every walk from a root ends
+// within the depth the layout reports.  Needs no GPU.
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../ray_tracing_amd/csrc/gpu_layout.hpp"
+
+using namespace rt;
+
+static uint64_t g_state = 0xD1B54A32D192ED03ull;
+static uint32_t rnd() {
+    g_state ^= g_state << 13;
+    g_state ^= g_state >> 7;
+    g_state ^= g_state << 17;
+    return (uint32_t)(g_state >> 16);
+}
+static float rndf(float lo, float hi) { return lo + (hi - lo) * (float)(rnd() & 0xFFFFFF) / 16777215.0f; }
+
+#define CHECK(cond)                                                              \
+    do {                                                                         \
+        if (!(cond)) {                                                           \
+            std::fprintf(stderr, "CHECK failed line %d: %s\n", __LINE__, #cond); \
+            std::exit(1);                                                        \
+        }                                                                        \
+    } while (0)
+
+// every link of a node record in range; returns the depth below it (recursion bounded by the claim)
+static uint32_t walk(const GpuScene& g, const DevNode& n, int k, uint32_t depth_left) {
+    if (n.b[k] == kInternalTag) {
+        CHECK(n.a[k] < g.nodes.size());
+        CHECK(depth_left > 0);
+        const DevNode& c = g.nodes[n.a[k]];
+        const uint32_t d0 = walk(g, c, 0, depth_left - 1), d1 = walk(g, c, 1, depth_left - 1);
+        return 1u + (d0 > d1 ? d0 : d1);
+    }
+    if (n.a[k] <= n.b[k]) CHECK(n.b[k] < g.tris.size() && n.b[k] < g.tri_tests.size());
+    return 1u;
+}
+
+int main(int argc, char** argv) {
+    const int rounds = argc > 1 ? std::atoi(argv[1]) : 2000;
+    int accepted = 0;
+    for (int r = 0; r < rounds; ++r) {
+        const bool sane = rnd() % 3 != 0;  // mostly well-formed scenes with a few defects, else plain noise
+        const size_t nv = 3 + rnd() % 40, nt = 1 + rnd() % 60, nb = 1 + rnd() % 40, no = 1 + rnd() % 3, ni = 1 + rnd() % 4;
+        std::vector<rt_vertex> v(nv);
+        for (auto& x : v) {
+            std::memset(&x, 0, sizeof x);
+            for (int k = 0; k < 3; ++k) x.pos[k] = rndf(-4, 4);
+        }
+        if (rnd() % 11 == 0) v[rnd() % nv].pos[rnd() % 3] = rnd() % 2 ? NAN : INFINITY;
+        std::vector<rt_tri> t(nt);
+        for (auto& f : t) {
+            f.i0 = rnd() % nv;
+            f.i1 = rnd() % nv;
+            f.i2 = rnd() % nv;
+        }
+        if (rnd() % 7 == 0) t[rnd() % nt].i1 = (uint32_t)nv + rnd() % 3;
+        std::vector<rt_bvh> b(nb);
+        for (size_t i = 0; i < nb; ++i) {
+            rt_bvh& n = b[i];
+            std::memset(&n, 0, sizeof n);
+            for (int k = 0; k < 3; ++k) {
+                n.bounding_box.min[k] = rndf(-5, 0);
+                n.bounding_box.max[k] = rndf(0, 5);
+            }
+            if (sane && 2 * i + 2 < nb) {
+                n.mode = RT_MODE_CHILDREN;
+                n.child_1_or_first_tri = (uint32_t)(2 * i + 1);
+                n.child_2_or_last_tri = (uint32_t)(2 * i + 2);
+            } else if (sane) {
+                n.mode = RT_MODE_TRIANGLES;
+                n.child_1_or_first_tri = rnd() % nt;
+                n.child_2_or_last_tri = n.child_1_or_first_tri + rnd() % (nt - n.child_1_or_first_tri);
+            } else {
+                n.mode = rnd() % 3;
+                n.child_1_or_first_tri = rnd() % (nb + 2);
+                n.child_2_or_last_tri = rnd() % 6 == 0 ? rnd() : rnd() % (nb + 2);
+            }
+        }
+        if (sane) {  // a few defects in an otherwise good tree
+            const int defects = (int)(rnd() % 3);
+            for (int d = 0; d < defects; ++d) {
+                rt_bvh& n = b[rnd() % nb];
+                switch (rnd() % 6) {
+                    case 0: n.child_1_or_first_tri = rnd() % (nb + 1); break;                 // cycle / shared child / off the end
+                    case 1: n.child_2_or_last_tri = rnd(); break;
+                    case 2: n.mode = rnd() % 4; break;
+                    case 3: n.bounding_box.min[rnd() % 3] = NAN; break;
+                    case 4: n.bounding_box.max[rnd() % 3] = -INFINITY; break;
+                    default: n.child_2_or_last_tri = n.child_1_or_first_tri - 1; break;       // an empty range
+                }
+            }
+        }
+        std::vector<rt_object> o(no);
+        for (auto& x : o) x.bvh_root = sane ? 0u : rnd() % (nb + 1);
+        std::vector<rt_instance> inst(ni);
+        for (auto& x : inst) {
+            std::memset(&x, 0, sizeof x);
+            x.transform.x_axis[0] = rndf(0.5f, 2);
+            x.transform.y_axis[1] = rndf(0.5f, 2);
+            x.transform.z_axis[2] = rnd() % 13 == 0 ? 0.0f : rndf(0.5f, 2);  // now and then singular
+            x.transform.translation[0] = rnd() % 17 == 0 ? NAN : rndf(-3, 3);
+            x.object_id = rnd() % 9 == 0 ? (uint32_t)no + rnd() % 2 : rnd() % no;
+        }
+        rt_scene_info info;
+        std::memset(&info, 0, sizeof info);
+        info.num_instances = (uint32_t)ni;
+        info.num_bvh_nodes = (uint32_t)nb;
+        info.num_triangles = (uint32_t)nt;
+        if (rnd() % 15 == 0) info.num_instances += 1;  // counts that disagree with the buffers
+        if (rnd() % 15 == 0) info.num_triangles -= 1;
+        GpuScene g;
+        std::string err;
+        const bool ok = build_gpu_scene(info, v.data(), nv, t.data(), nt, o.data(), no, inst.data(), ni, b.data(), nb, g, err);
+        if (!ok) {
+            CHECK(!err.empty());
+            continue;
+        }
+        ++accepted;
+        CHECK(g.instances.size() == ni && g.objects.size() == no && g.tris.size() == nt && g.tri_tests.size() == nt);
+        CHECK(g.max_depth >= 1);
+        for (const DevObject& ob : g.objects) CHECK(walk(g, ob.root, 0, g.max_depth) <= g.max_depth);
+        for (const DevInstance& di : g.instances) {
+            CHECK(di.object_id < no);
+            CHECK(std::memcmp(&di.root, &g.objects[di.object_id].root, sizeof(DevNode)) == 0);
+            CHECK(walk(g, di.root, 0, g.max_depth) <= g.max_depth);
+        }
+    }
+    std::printf("layout fuzz ok: %d of %d scenes accepted\n", accepted, rounds);
+    return 0;
+}

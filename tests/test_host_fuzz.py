@@ -22,3 +22,18 @@ def test_host_sources_survive_mutated_input_under_sanitizers():
                          text=True, timeout=600)
     assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-4000:]
     assert "host fuzz ok" in run.stdout
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="no host compiler")
+def test_scene_check_refuses_or_bounds_every_arbitrary_scene_under_sanitizers():
+    """build_gpu_scene, which every upload goes through, on 100 000 arbitrary scenes (cycles, shared
+    children, ranges off the end, non-finite boxes and transforms, counts that disagree): each is
+    refused, or comes out as a layout whose every link is in range and whose walks end within the
+    reported depth -- checked by the driver, under AddressSanitizer and UBSan."""
+    built = subprocess.run(["make", "-C", FUZZ, "_build/fuzz_layout"], capture_output=True, text=True, timeout=600)
+    assert built.returncode == 0, built.stdout[-2000:] + built.stderr[-2000:]
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:verify_asan_link_order=0", UBSAN_OPTIONS="print_stacktrace=1")
+    run = subprocess.run([os.path.join(FUZZ, "_build", "fuzz_layout"), "100000"], cwd=ROOT, env=env, capture_output=True,
+                         text=True, timeout=600)
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-4000:]
+    assert "layout fuzz ok" in run.stdout
