@@ -37,3 +37,19 @@ def test_scene_check_refuses_or_bounds_every_arbitrary_scene_under_sanitizers():
                          text=True, timeout=600)
     assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-4000:]
     assert "layout fuzz ok" in run.stdout
+
+
+@pytest.mark.gpu
+def test_context_lifecycle_under_host_sanitizers():
+    """tests/host_fuzz/fuzz_ctx: random sequences of uploads, option changes, renders on canvases of
+    changing size, read-backs, the two-step present, updates, partitions and destroy / create through
+    the C ABI, with the context's host code under AddressSanitizer (leak check included) and UBSan.
+    The driver is built beforehand (__graft_entry__.build), not here."""
+    exe = os.path.join(FUZZ, "_build", "fuzz_ctx")
+    if not os.path.exists(exe):
+        pytest.skip("tests/host_fuzz/_build/fuzz_ctx is not built")
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:verify_asan_link_order=0", UBSAN_OPTIONS="print_stacktrace=1",
+               LSAN_OPTIONS="suppressions=" + os.path.join(FUZZ, "lsan.supp") + ":print_suppressions=0")
+    run = subprocess.run([exe, "1500"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=280)
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-4000:]
+    assert "context fuzz ok" in run.stdout
