@@ -52,6 +52,8 @@ int main(int argc, char** argv) {
     bool have_scene = false;
     uint32_t rendered_w = 0, rendered_h = 0;  // canvas of the last render, 0: nothing rendered since the last change
     bool begun = false;
+    bool probe_on = false, counters_on = false, probed = false, counted = false;  // options, and whether a render has run with them
+    std::vector<rt_instance> inst_copy;
 
     auto new_cam = [&](uint32_t w, uint32_t h) {
         std::memset(&cam, 0, sizeof cam);
@@ -83,6 +85,17 @@ int main(int argc, char** argv) {
             n_inst += k;
         }
         CHECK(rt_upload_scene_from_builder(ctx, b) == RT_OK);
+        {
+            rt_scene_info info;
+            const rt_vertex* pv;
+            const rt_tri* pt;
+            const rt_object* po;
+            const rt_instance* pi;
+            const rt_bvh* pb;
+            size_t cv, ct, co, ci, cb;
+            CHECK(rt_scene_builder_build(b, &info, &pv, &cv, &pt, &ct, &po, &co, &pi, &ci, &pb, &cb) == RT_OK && ci == n_inst);
+            inst_copy.assign(pi, pi + ci);
+        }
         rt_scene_builder_free(b);
         have_scene = true;
     };
@@ -92,14 +105,14 @@ int main(int argc, char** argv) {
     std::vector<float> img;
     std::vector<uint8_t> img8;
     for (int r = 0; r < rounds; ++r) {
-        switch (rnd() % 14) {
+        switch (rnd() % 17) {
             case 0:
                 upload();
                 break;
             case 1: {  // another canvas
                 new_cam(8 + rnd() % 120, 8 + rnd() % 70);
                 rendered_w = rendered_h = 0;
-                begun = false;
+                begun = probed = counted = false;
                 break;
             }
             case 2:
@@ -108,12 +121,16 @@ int main(int argc, char** argv) {
                 CHECK(rt_render_frames(ctx, &cam, n) == RT_OK);
                 rendered_w = cam.canvas_width;
                 rendered_h = cam.canvas_height;
+                probed = probe_on;
+                counted = counters_on;
                 break;
             }
             case 4:
                 CHECK(rt_render_frame(ctx, &cam) == RT_OK);
                 rendered_w = cam.canvas_width;
                 rendered_h = cam.canvas_height;
+                probed = probe_on;
+                counted = counters_on;
                 break;
             case 5:
                 if (rendered_w) {
@@ -150,6 +167,8 @@ int main(int argc, char** argv) {
                 const int o = opt[rnd() % 6];
                 const int64_t v = o == RT_OPT_PIPELINE ? rnd() % 3 : o == RT_OPT_TILE_DEAL ? (int64_t)(rnd() % 3) - 1 : rnd() % 2;
                 CHECK(rt_set_option(ctx, o, v) == RT_OK);
+                if (o == RT_OPT_PROBE_HITS) probe_on = v != 0, probed = false;
+                if (o == RT_OPT_COUNTERS) counters_on = v != 0, counted = false;
                 if (o == RT_OPT_PRESENT && v == 0) {
                     rendered_w = rendered_h = 0;  // no presented image until the option is back on and a frame rendered
                     begun = false;
@@ -178,6 +197,32 @@ int main(int argc, char** argv) {
                 CHECK(rt_synchronize(ctx) == RT_OK);
                 break;
             }
+            case 13: {  // the instances move (what the reference does by refilling its instance buffer)
+                for (auto& x : inst_copy) x.transform.translation[1] = (float)(rnd() % 7) - 3.0f;
+                CHECK(rt_update_instances(ctx, inst_copy.data(), inst_copy.size()) == RT_OK);
+                CHECK(rt_update_instances(ctx, inst_copy.data(), inst_copy.size() + 1) != RT_OK);
+                break;
+            }
+            case 14:
+                if (rendered_w && probed && counted) {
+                    const size_t n = (size_t)rendered_w * rendered_h;
+                    std::vector<uint32_t> a(n), b2(n), c2(n);
+                    CHECK(rt_read_hits(ctx, a.data(), b2.data(), c2.data(), n) == RT_OK);
+                    CHECK(rt_read_counters(ctx, a.data(), b2.data(), n) == RT_OK);
+                    CHECK(rt_read_hits(ctx, a.data(), b2.data(), c2.data(), n - 1) != RT_OK);
+                }
+                break;
+            case 15: {  // the caller's own accumulator, on a canvas of its own
+                const uint32_t w = 8 + rnd() % 40, h = 8 + rnd() % 30;
+                std::vector<float> acc((size_t)w * h * 4, 0.25f);
+                CHECK(rt_write_acc(ctx, acc.data(), (size_t)w * h, w, h) == RT_OK);
+                CHECK(rt_write_acc(ctx, acc.data(), (size_t)w * h + 1, w, h) != RT_OK);
+                new_cam(w, h);
+                cam.frames_without_move = 1.0f;
+                rendered_w = rendered_h = 0;
+                begun = probed = counted = false;
+                break;
+            }
             default: {  // a new context now and then
                 if (rnd() % 4 == 0) {
                     rt_destroy(ctx);
@@ -185,7 +230,7 @@ int main(int argc, char** argv) {
                     CHECK(rt_create(0, &ctx) == RT_OK);
                     have_scene = false;
                     rendered_w = rendered_h = 0;
-                    begun = false;
+                    begun = probed = counted = probe_on = counters_on = false;
                     CHECK(rt_render_frame(ctx, &cam) == RT_ERR_NO_SCENE);
                     upload();
                 }
