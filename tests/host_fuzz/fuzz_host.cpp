@@ -249,6 +249,49 @@ int main(int argc, char** argv) {
         }
         rt_scene_builder_free(b);
     }
+    // one mesh large enough for the host builder to hand subtrees to helper threads (the race
+    // detector's part of the job): the tree must not depend on the number of threads
+    if (argc > 3) {
+        const size_t side = (size_t)std::atoi(argv[3]);
+        std::vector<rt_vertex> v((side + 1) * (side + 1));
+        for (size_t i = 0; i <= side; ++i)
+            for (size_t j = 0; j <= side; ++j) {
+                rt_vertex& x = v[i * (side + 1) + j];
+                std::memset(&x, 0, sizeof x);
+                x.pos[0] = (float)j;
+                x.pos[1] = rndf(0, 3);
+                x.pos[2] = (float)i;
+            }
+        std::vector<rt_tri> t0;
+        for (size_t i = 0; i < side; ++i)
+            for (size_t j = 0; j < side; ++j) {
+                const uint32_t a = (uint32_t)(i * (side + 1) + j), b = a + 1, c = a + (uint32_t)side + 1, d = c + 1;
+                t0.push_back(rt_tri{a, b, c});
+                t0.push_back(rt_tri{b, d, c});
+            }
+        std::vector<rt_bvh> first;
+        std::vector<rt_tri> first_t;
+        for (int threads : {1, 4, 3}) {
+            std::vector<rt_tri> t = t0;
+            rt_bvh_params p;
+            rt_bvh_params_default(&p);
+            p.leaf_max = 4;
+            p.threads = threads;
+            size_t n_nodes = 2 * t.size();
+            std::vector<rt_bvh> nodes(n_nodes);
+            CHECK(rt_create_bvh(v.data(), v.size(), t.data(), t.size(), &p, nodes.data(), &n_nodes) == RT_OK);
+            nodes.resize(n_nodes);
+            check_tree(nodes, n_nodes, t.size());
+            if (threads == 1) {
+                first = nodes;
+                first_t = t;
+            } else {
+                CHECK(nodes.size() == first.size() && std::memcmp(nodes.data(), first.data(), nodes.size() * sizeof(rt_bvh)) == 0);
+                CHECK(std::memcmp(t.data(), first_t.data(), t.size() * sizeof(rt_tri)) == 0);
+            }
+        }
+        std::printf("threaded build of %zu triangles: the same tree with 1, 4 and 3 threads\n", t0.size());
+    }
     std::printf("ready-made trees: %d of %d taken\n", taken, rounds);
     std::printf("host fuzz ok: %d texts parsed, %d refused, %d random meshes\n", parsed, refused, rounds);
     return 0;
