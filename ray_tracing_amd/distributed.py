@@ -61,7 +61,9 @@ def gather_strips(local_image, strip_h, group=None, dst=0):
 
 def reduce_samples(acc, group=None):
     """Sum the per-rank accumulation buffers in place on every rank (sample mode):
-    one all-reduce of 4*W*H floats (1080p: 33 MB, 4K: 133 MB)."""
+    one all-reduce of 4*W*H floats (1080p: 33 MB, 4K: 133 MB).  The collective is ordered after the
+    work on torch's current stream of the tensor's device: render on that stream (App.create(...,
+    stream=torch.cuda.current_stream().cuda_stream)) or synchronize the context first."""
     import torch.distributed as dist
 
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
