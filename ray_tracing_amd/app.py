@@ -29,6 +29,7 @@ class App:
             msg = self._lib.rt_last_error(None).decode()
             self._ctx = None
             raise L.RtError(rc, msg)
+        self.device = int(device)
         self.cam_data = cam_data
         self.orientation = (C.c_float * 2)(0.0, 0.0)  # vulkan.rs:84, 161
         self.scene = None
@@ -221,7 +222,7 @@ class App:
             __cuda_array_interface__ = {"shape": (h, w, 4), "typestr": "<f4", "data": (self.acc_device_ptr(), False),
                                         "version": 2, "strides": None}
 
-        return torch.as_tensor(_Alias(), device=torch.device("cuda", torch.cuda.current_device()))
+        return torch.as_tensor(_Alias(), device=torch.device("cuda", self.device))  # the context's GPU, whatever torch's current one is
 
     def last_render_ms(self):
         ms = C.c_float()
