@@ -249,6 +249,34 @@ int main(int argc, char** argv) {
         }
         rt_scene_builder_free(b);
     }
+    // the image writers on canvases of every small size, with values no display can show
+    {
+        const std::string png = "/tmp/rt_host_fuzz.png", exr = "/tmp/rt_host_fuzz.exr";
+        const int n_images = rounds < 60 ? rounds : 60;
+        for (int r = 0; r < n_images; ++r) {
+            const uint32_t w = 1 + rnd() % 70, h = 1 + rnd() % 50;
+            std::vector<float> img((size_t)w * h * 4);
+            for (auto& x : img) {
+                switch (rnd() % 12) {
+                    case 0: x = NAN; break;
+                    case 1: x = INFINITY; break;
+                    case 2: x = -INFINITY; break;
+                    case 3: x = -rndf(0, 10); break;
+                    case 4: x = rndf(1, 1.0e30f); break;
+                    default: x = rndf(0, 1);
+                }
+            }
+            CHECK(rt_save_png(png.c_str(), img.data(), w, h) == RT_OK);
+            CHECK(rt_save_exr(exr.c_str(), img.data(), w, h, rndf(0, 2)) == RT_OK);
+            CHECK(slurp(png.c_str()).size() > 8 && slurp(exr.c_str()).size() > (size_t)w * h * 12);
+        }
+        CHECK(rt_save_png("/nonexistent-directory/x.png", nullptr, 4, 4) != RT_OK);
+        float one[4] = {0, 0, 0, 1};
+        CHECK(rt_save_png("/nonexistent-directory/x.png", one, 1, 1) == RT_ERR_IO);
+        CHECK(rt_save_png(png.c_str(), one, 0, 1) != RT_OK);
+        std::remove(png.c_str());
+        std::remove(exr.c_str());
+    }
     // one mesh large enough for the host builder to hand subtrees to helper threads (the race
     // detector's part of the job): the tree must not depend on the number of threads
     if (argc > 3) {
