@@ -1,6 +1,9 @@
 #include "gpu_layout.hpp"
 
+#include <algorithm>
+#include <atomic>
 #include <cstring>
+#include <thread>
 
 #include "fastdiv.hpp"
 #include "host_math.hpp"
@@ -116,29 +119,51 @@ bool build_gpu_scene(const rt_scene_info& info, const rt_vertex* vertices, size_
     }
 
     // triangles: gather the vertices, precompute the plane (hit.rs:145-148)
+    // (every triangle on its own: large scenes share the range out over host threads)
     out.tris.resize(n_triangles);
     out.tri_tests.resize(n_triangles);
-    for (size_t i = 0; i < n_triangles; ++i) {
-        const rt_tri& t = triangles[i];
-        if (t.i0 >= n_vertices || t.i1 >= n_vertices || t.i2 >= n_vertices) {
-            err = "triangle " + std::to_string(i) + " references a vertex out of range";
-            return false;
+    std::atomic<size_t> first_bad{n_triangles};
+    auto triangle_range = [&](size_t begin, size_t end) {
+        for (size_t i = begin; i < end; ++i) {
+            const rt_tri& t = triangles[i];
+            if (t.i0 >= n_vertices || t.i1 >= n_vertices || t.i2 >= n_vertices) {
+                size_t seen = first_bad.load();
+                while (i < seen && !first_bad.compare_exchange_weak(seen, i)) {
+                }
+                return;
+            }
+            V3 p0 = ld(vertices[t.i0].pos), p1 = ld(vertices[t.i1].pos), p2 = ld(vertices[t.i2].pos);
+            V3 a = p1 - p0, b = p2 - p0;
+            V3 normal = normalize(cross(a, b));
+            float d = -(dot(normal, p0));
+            DevTri& o = out.tris[i];
+            st(o.p0, p0);
+            st(o.p1, p1);
+            st(o.p2, p2);
+            o.nx = normal.x;
+            o.ny = normal.y;
+            o.nz = normal.z;
+            o.d = d;
+            o.pad[0] = o.pad[1] = o.pad[2] = 0.0f;
+            const float nf[3] = {normal.x, normal.y, normal.z};
+            tri_filter_build(o.p0, o.p1, o.p2, nf, d, out.tri_tests[i]);
         }
-        V3 p0 = ld(vertices[t.i0].pos), p1 = ld(vertices[t.i1].pos), p2 = ld(vertices[t.i2].pos);
-        V3 a = p1 - p0, b = p2 - p0;
-        V3 normal = normalize(cross(a, b));
-        float d = -(dot(normal, p0));
-        DevTri& o = out.tris[i];
-        st(o.p0, p0);
-        st(o.p1, p1);
-        st(o.p2, p2);
-        o.nx = normal.x;
-        o.ny = normal.y;
-        o.nz = normal.z;
-        o.d = d;
-        o.pad[0] = o.pad[1] = o.pad[2] = 0.0f;
-        const float nf[3] = {normal.x, normal.y, normal.z};
-        tri_filter_build(o.p0, o.p1, o.p2, nf, d, out.tri_tests[i]);
+    };
+    const size_t per_thread = 65536;
+    const size_t n_workers = std::min<size_t>({(n_triangles + per_thread - 1) / per_thread,
+                                               std::max(1u, std::thread::hardware_concurrency()), 16});
+    if (n_workers <= 1) {
+        triangle_range(0, n_triangles);
+    } else {
+        std::vector<std::thread> workers;
+        const size_t share = (n_triangles + n_workers - 1) / n_workers;
+        for (size_t w = 0; w < n_workers; ++w)
+            workers.emplace_back(triangle_range, std::min(w * share, n_triangles), std::min((w + 1) * share, n_triangles));
+        for (auto& th : workers) th.join();
+    }
+    if (first_bad.load() < n_triangles) {
+        err = "triangle " + std::to_string(first_bad.load()) + " references a vertex out of range";
+        return false;
     }
 
     // internal nodes get dense indices in input order

@@ -135,6 +135,61 @@ int main(int argc, char** argv) {
             CHECK(walk(g, di.root, 0, g.max_depth) <= g.max_depth);
         }
     }
+    // a scene large enough for the per-triangle pass to be shared out over host threads: the same
+    // records as from one thread's worth at a time, and the FIRST bad triangle named whatever thread met it
+    {
+        const size_t nv = 1000, nt = 300000;
+        std::vector<rt_vertex> v(nv);
+        for (auto& x : v) {
+            std::memset(&x, 0, sizeof x);
+            for (int k = 0; k < 3; ++k) x.pos[k] = rndf(-4, 4);
+        }
+        std::vector<rt_tri> t(nt);
+        for (auto& f : t) {
+            f.i0 = rnd() % nv;
+            f.i1 = rnd() % nv;
+            f.i2 = rnd() % nv;
+        }
+        rt_bvh leaf;
+        std::memset(&leaf, 0, sizeof leaf);
+        for (int k = 0; k < 3; ++k) {
+            leaf.bounding_box.min[k] = -4;
+            leaf.bounding_box.max[k] = 4;
+        }
+        leaf.mode = RT_MODE_TRIANGLES;
+        leaf.child_2_or_last_tri = (uint32_t)nt - 1;
+        rt_object o = {0};
+        rt_instance inst;
+        std::memset(&inst, 0, sizeof inst);
+        inst.transform.x_axis[0] = inst.transform.y_axis[1] = inst.transform.z_axis[2] = 1.0f;
+        rt_scene_info info;
+        std::memset(&info, 0, sizeof info);
+        info.num_instances = 1;
+        info.num_bvh_nodes = 1;
+        info.num_triangles = (uint32_t)nt;
+        GpuScene big;
+        std::string err;
+        CHECK(build_gpu_scene(info, v.data(), nv, t.data(), nt, &o, 1, &inst, 1, &leaf, 1, big, err));
+        // every record equals the one a scene of that triangle alone gets (built on the calling thread)
+        for (int probe = 0; probe < 200; ++probe) {
+            const size_t i = rnd() % nt;
+            rt_bvh one = leaf;
+            one.child_2_or_last_tri = 0;
+            info.num_triangles = 1;
+            GpuScene g1;
+            CHECK(build_gpu_scene(info, v.data(), nv, &t[i], 1, &o, 1, &inst, 1, &one, 1, g1, err));
+            CHECK(std::memcmp(&g1.tris[0], &big.tris[i], sizeof(DevTri)) == 0);
+            CHECK(std::memcmp(&g1.tri_tests[0], &big.tri_tests[i], sizeof(DevTriTest)) == 0);
+        }
+        info.num_triangles = (uint32_t)nt;
+        t[200000].i0 = (uint32_t)nv;
+        t[123456].i1 = (uint32_t)nv + 7;
+        t[299999].i2 = 0xFFFFFFFFu;
+        GpuScene bad;
+        CHECK(!build_gpu_scene(info, v.data(), nv, t.data(), nt, &o, 1, &inst, 1, &leaf, 1, bad, err));
+        CHECK(err.find("triangle 123456 ") != std::string::npos);
+        std::printf("threaded layout of %zu triangles ok\n", nt);
+    }
     std::printf("layout fuzz ok: %d of %d scenes accepted\n", accepted, rounds);
     return 0;
 }

@@ -52,6 +52,13 @@ def test_threaded_host_build_under_the_race_detector():
                          cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-4000:]
     assert "the same tree with 1, 4 and 3 threads" in run.stdout and "ThreadSanitizer" not in run.stderr
+    # the scene check shares its per-triangle pass out over host threads as well
+    built = subprocess.run(["make", "-C", FUZZ, "_build/fuzz_layout_tsan"], capture_output=True, text=True, timeout=600)
+    assert built.returncode == 0, built.stdout[-2000:] + built.stderr[-2000:]
+    run = subprocess.run([os.path.join(FUZZ, "_build", "fuzz_layout_tsan"), "200"], cwd=ROOT, capture_output=True, text=True,
+                         timeout=600)
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-4000:]
+    assert "threaded layout of 300000 triangles ok" in run.stdout and "ThreadSanitizer" not in run.stderr
 
 
 @pytest.mark.gpu
