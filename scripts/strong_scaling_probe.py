@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""How long one GPU takes for its share of the bench job when the canvas is dealt to `world`
-GPUs in 8-row strips (the share of rank 0), against 1/world of the one-GPU time.  One GPU only:
-rehearses the per-GPU work of the N-GPU bench without N GPUs."""
+"""How long the bench job takes when its canvas is dealt to `world` GPUs in 8-row strips: every rank's
+share is rendered alone on this one GPU and the slowest one is the job's time (the ranks of a real run
+work side by side and the barrier waits for the last).  Rehearses the N-GPU bench without N GPUs;
+the tree comes from the bench's default builder."""
 import os
 import sys
 
@@ -10,19 +11,23 @@ import bench  # noqa: E402
 from ray_tracing_amd import App  # noqa: E402
 from ray_tracing_amd import _lib as L  # noqa: E402
 
-scene, cam0, _ = bench.build_scene("c3", 4, 16, 700)
+scene, cam0, _ = bench.build_scene("c3", 4, 16, 700, builder="gpu_sah")
 app = App.create(L.CamData.from_buffer_copy(cam0), scene)
 base = None
-for world in (1, 2, 4, 8):
-    app.set_rows(8, 0, world)
-    times = []
-    for _ in range(4):
-        app.cam_data = L.CamData.from_buffer_copy(cam0)
-        app.clear_acc()
-        app.render_frames(16)
-        app.synchronize()
-        times.append(app.last_render_ms())
-    t = min(times[1:])
+for world in (1, 2, 4, 8, 16, 64):
+    per_rank = []
+    for rank in range(world):
+        app.set_rows(8, rank, world)
+        times = []
+        for _ in range(3):
+            app.cam_data = L.CamData.from_buffer_copy(cam0)
+            app.clear_acc()
+            app.render_frames(16)
+            app.synchronize()
+            times.append(app.last_render_ms())
+        per_rank.append(min(times[1:]))
+    t = max(per_rank)
     base = base or t
-    print(f"world {world}: {t:.2f} ms for rank 0's rows; ideal {base / world:.2f} ms; efficiency {base / world / t:.2f}", flush=True)
+    print(f"world {world}: slowest rank {per_rank.index(t)} {t:.2f} ms, fastest {min(per_rank):.2f} ms, mean "
+          f"{sum(per_rank) / world:.2f} ms; ideal {base / world:.2f} ms; efficiency {base / world / t:.2f}", flush=True)
 app.destroy()
