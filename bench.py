@@ -279,6 +279,21 @@ def main():
     elapsed, total_rays, kernel_ms = timed(args.steps, one_step)
     ms_per_step = elapsed / args.steps * 1e3
 
+    def strong_scaling_floor():
+        """What no number of GPUs gets below: the slowest of the 64 shares of a 64-way split, each rendered
+        alone on this GPU (the share that holds the dearest pixels: a pixel's frames and segments are one
+        chain of dependent steps however few pixels keep it company)."""
+        shares = []
+        for r in range(64):
+            app.set_rows(STRIP_H, r, 64)
+            one_step()  # learns this share's tile order
+            dt, _, _ = timed(1, one_step)
+            shares.append(dt * 1e3)
+        app.set_rows(STRIP_H, rank, world)
+        return {"share_of_canvas": 1.0 / 64, "ms_per_step": max(shares), "slowest_rank": shares.index(max(shares)),
+                "mean_ms_per_step": sum(shares) / len(shares),
+                "what": "step time of the slowest of the 64 shares of a 64-way split, each rendered alone on one GPU"}
+
     extras = {}
     if first_launch:
         extras["first_launch_of_a_view"] = first_launch
@@ -298,20 +313,7 @@ def main():
             lone_frames()
         dt, _, _ = timed(3, lone_frames)
         extras["ms_per_lone_frame"] = dt / 3 / frames_per_step * 1e3
-        # what no number of GPUs gets below: the slowest of the 64 shares of a 64-way split, each rendered
-        # alone on this GPU (the share that holds the dearest pixels: a pixel's frames and segments are one
-        # chain of dependent steps however few pixels keep it company)
-        shares = []
-        for r in range(64):
-            app.set_rows(STRIP_H, r, 64)
-            one_step()  # learns this share's tile order
-            dt, rays, ms = timed(1, one_step)
-            shares.append(dt * 1e3)
-        extras["strong_scaling_floor"] = {"share_of_canvas": 1.0 / 64, "ms_per_step": max(shares),
-                                          "slowest_rank": shares.index(max(shares)),
-                                          "mean_ms_per_step": sum(shares) / len(shares),
-                                          "what": "step time of the slowest of the 64 shares of a 64-way split, each rendered alone"}
-        app.set_rows(STRIP_H, rank, world)
+        extras["strong_scaling_floor"] = strong_scaling_floor()
     if world > 1 and partition == "tile" and scaling == "strong" and not args.no_extras:
         # weak scaling beside the headline: the same view on N times the area
         ww, wh = canvas_for(args.config, world, "weak")
@@ -332,6 +334,8 @@ def main():
         dt, rays, ms = timed(max(2, args.steps // 2), weak_step)
         extras["weak_scaling"] = {"canvas": [ww, wh], "Mrays_per_s": rays / dt / 1e6,
                                   "ms_per_step": dt / max(2, args.steps // 2) * 1e3}
+        # why the headline does not scale: the job's longest chain of dependent steps, on one GPU
+        extras["strong_scaling_floor"] = strong_scaling_floor()
 
     def same_job_on_another_tree(builder, leaf_max):
         """The headline's scene, camera and frames with the terrain's tree from another builder."""
