@@ -136,7 +136,10 @@ int rt_set_rows(rt_ctx* ctx, uint32_t strip_height, uint32_t rank, uint32_t worl
 
 /* ---- render: App::render minus the swapchain (vulkan.rs:171-236); one
  *      sample per pixel with the accumulate/reset rule of shader/src/lib.rs:85-98.
- *      Asynchronous on the context's stream. ---- */
+ *      Asynchronous on the context's stream.  Canvases of at least one and fewer
+ *      than 2^31 pixels (RT_ERR_INVALID otherwise) in fewer than 2^26 tiles of 8x8
+ *      pixels (RT_ERR_LIMIT).  depth 0 renders black without tracing a ray
+ *      (trace.rs:193-205). ---- */
 int rt_render_frame(rt_ctx* ctx, const rt_cam_data* cam);
 /* n consecutive frames; after each one frame += 1 and frames_without_move += 1.0
  * exactly as the event loop does (main.rs:147-148).  *cam is updated. */

@@ -248,6 +248,10 @@ int render(rt_ctx* c, const rt_cam_data& cam, uint32_t n_frames, const DevFrame*
     if (!c->have_scene) return fail(c, RT_ERR_NO_SCENE, "rt_upload_scene has not been called");
     if (cam.debug_information > RT_DEBUG_BVH_INTERSECTION) return fail(c, RT_ERR_INVALID, "bad debug_information");
     const bool own_buffers = caller_frame == nullptr;
+    // the work queues name a pixel slot by 32 bits: 64 slots per 8x8 tile (a canvas of one row still
+    // takes a tile per 8 pixels)
+    if (((uint64_t)cam.canvas_width + 7u) / 8u * (((uint64_t)cam.canvas_height + 7u) / 8u) >= (1ull << 26))
+        return fail(c, RT_ERR_LIMIT, "canvas of 2^26 or more 8x8 tiles");
     if (own_buffers) {
         int rc = ensure_frame(c, cam.canvas_width, cam.canvas_height);
         if (rc != RT_OK) return rc;

@@ -114,6 +114,12 @@ def test_extreme_camera_fields_and_a_singular_instance():
         with pytest.raises(RtError) as e:
             gpu_render(scene, c, 1)
         assert e.value.code == L.RT_ERR_INVALID
+    # a canvas within the pixel limit whose 8x8 tiles no longer fit the queues' 32-bit slot numbers
+    c = copy_cam(cam)
+    c.canvas_width, c.canvas_height = 600_000_000, 1
+    with pytest.raises(RtError) as e:
+        gpu_render(scene, c, 1)
+    assert e.value.code == L.RT_ERR_LIMIT
 
 
 def test_a_scene_without_instances_is_refused():
