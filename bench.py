@@ -43,6 +43,47 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
 STRIP_H = 8
 
+# what the hardware counters of a committed profile depend on: the trace kernel and everything it
+# includes, and the code that makes the tree and the device records the kernel walks
+PROFILED_SOURCES = ("kernels.hip", "traverse_steps.inc", "instance_walk.inc", "trace_device.hpp", "fastdiv.hpp",
+                    "trifilter.hpp", "fastexact.hpp", "wave_scan.hpp", "device_types.hpp", "kernels.hpp", "Makefile",
+                    "bvh_sah_gpu.hip", "bvh_pad.hpp", "gpu_layout.cpp", "host_scene.cpp")
+
+
+def profiled_source_hash():
+    """SHA-256 over the sources a committed hardware-counter profile is only valid for."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for name in PROFILED_SOURCES:
+        with open(os.path.join(ROOT, "ray_tracing_amd", "csrc", name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read() + b"\0")
+    return h.hexdigest()
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` started plainly: start the N ranks as children (one process per
+    GPU, torch.distributed.run on 127.0.0.1) before anything in this process touches a GPU, pass rank
+    0's JSON line through as the only line on stdout, and return the children's worst exit code."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, min(os.cpu_count() or 1, 16) // n)))
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env, cwd=ROOT)
+    lines = [l for l in proc.stdout.splitlines() if l.lstrip().startswith("{")]
+    if lines:
+        print(lines[-1])
+    else:
+        sys.stderr.write(proc.stdout)
+    return proc.returncode if proc.returncode else (0 if lines else 1)
+
 CONFIGS = {
     # name: (width, height, frames per step, depth, partition)
     "c2": (1920, 1080, 1, 5, "tile"),
@@ -157,6 +198,9 @@ def main():
         import faulthandler
         faulthandler.dump_traceback_later(float(os.environ["RT_BENCH_WATCHDOG_S"]), exit=True)
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus))  # no launcher around us: be the launcher
+
     import torch
     import torch.distributed as dist
 
@@ -164,7 +208,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the trace path has no CPU fallback")
     # Rehearsal on a box with fewer GPUs than ranks: RT_BENCH_REHEARSE=1 puts every rank on GPU 0 and
@@ -233,7 +277,7 @@ def main():
         if events:
             events[1].record()
         if acc_view is not None:
-            reduce_samples(acc_view)  # RCCL over xGMI; the one exchange this mode has
+            reduce_samples(acc_view, dst=0)  # RCCL over xGMI; the one exchange this mode has (rank 0 holds the image)
 
     # --- counter pass (untimed): the reference's debug counters for one step --------------
     app.set_option(RT_OPT_COUNTERS, 1)
@@ -244,9 +288,13 @@ def main():
     sched = app.sched_stats()
     app.set_option(RT_OPT_COUNTERS, 0)
 
+    last_clock_mhz = None
+
     def timed(n_steps, step):
         """n_steps of `step` between two barriers; wall seconds (max over ranks), rays of all
-        ranks, and this rank's average HIP-event time per launch."""
+        ranks, and this rank's average HIP-event time per launch.  Leaves the shader clock the
+        launches ran at (from the kernel's own counters) in `last_clock_mhz`."""
+        nonlocal last_clock_mhz
         sync()
         app.reset_stats()
         # HIP events on the stream the kernel is launched on (torch's current stream was handed
@@ -258,6 +306,7 @@ def main():
         sync()
         dt = time.perf_counter() - t0
         ms = sum(a.elapsed_time(b) for a, b in ev) / max(1, n_steps)
+        last_clock_mhz = app.kernel_clock_mhz()
         red_dev = "cpu" if rehearse else "cuda"
         t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         r = torch.tensor([float(app.stats()["rays"])], dtype=torch.float64, device=red_dev)
@@ -278,6 +327,7 @@ def main():
         one_step()
     elapsed, total_rays, kernel_ms = timed(args.steps, one_step)
     ms_per_step = elapsed / args.steps * 1e3
+    kernel_clock_mhz = last_clock_mhz  # of the timed region's launches
 
     def strong_scaling_floor():
         """What no number of GPUs gets below: the slowest of the 64 shares of a 64-way split, each rendered
@@ -336,6 +386,21 @@ def main():
                                   "ms_per_step": dt / max(2, args.steps // 2) * 1e3}
         # why the headline does not scale: the job's longest chain of dependent steps, on one GPU
         extras["strong_scaling_floor"] = strong_scaling_floor()
+    if world > 1 and partition == "tile" and not args.no_extras:
+        # the frame brought to one place: every rank's strips gathered on rank 0, device to device (one
+        # gather over RCCL; host memory and gloo in a one-GPU rehearsal).  Outside `value`: the
+        # metric counts rays traced, and a displayed frame needs this once, not once per sample.
+        from ray_tracing_amd.distributed import gather_strips
+        app.cam_data = fresh_cam()
+        app.clear_acc()
+        launch()
+        local = torch.from_numpy(app.read_acc()) if rehearse else app.acc_tensor()
+        sync()
+        t0 = time.perf_counter()
+        full = gather_strips(local, STRIP_H, dst=0)
+        sync()
+        extras["gather_ms"] = (time.perf_counter() - t0) * 1e3
+        extras["gathered_image_on_rank0"] = list(full.shape) if full is not None else None
 
     def same_job_on_another_tree(builder, leaf_max):
         """The headline's scene, camera and frames with the terrain's tree from another builder."""
@@ -369,29 +434,40 @@ def main():
             extras["reference_builder_tree"] = same_job_on_another_tree("host", 16)
 
     def committed_profile():
-        """Per-launch hardware counters of this very workload from the committed rocprofv3 PMC
-        passes (profiles/counters_bench.json); {} when no matching profile exists."""
+        """Per-launch hardware counters of this very workload from the committed rocprofv3 PMC passes
+        (profiles/counters_bench.json), and why they cannot be used when they cannot: the counters
+        are only valid for the sources they were taken on (a hash of the kernel, tree-builder and
+        layout sources rides in the file) and for the very traversal this run counted."""
         try:
             with open(os.path.join(ROOT, "profiles", "counters_bench.json")) as f:
                 tr = json.load(f)
-            if tr["workload"] == workload and tr["n_gpus"] == 1:
-                return tr
-        except (OSError, KeyError, ValueError):
-            pass
-        return {}
+        except (OSError, ValueError):
+            return {}, "no committed profile (profiles/counters_bench.json)"
+        if tr.get("workload") != workload or tr.get("n_gpus") != 1:
+            return {}, "the committed profile is of another workload"
+        if tr.get("source_hash") != profiled_source_hash():
+            return {}, "the kernel or builder sources changed after the committed profile was taken"
+        want = tr.get("counters_per_launch") or {}
+        if world == 1 and any(int(want.get(k, -1)) != int(counted[k]) for k in ("rays", "box_tests", "internal_visits", "triangle_tests")):
+            return {}, "this run's traversal counters differ from those of the committed profile"
+        return tr, None
 
     out = None
     if rank == 0:
         # The one kernel of the step, on this rank's share of the work.  It is bound by vector
-        # instruction issue: `peak` is what the chip issues of full-rate vector instructions
-        # (v_mul_f32 / v_add_f32, 2 cycles per SIMD) at the kernel's own occupancy, measured now by
-        # the device micro-probe; `achieved` is the kernel's vector instructions per launch (hardware
-        # counter of the committed profile of this workload) over its HIP-event time.
-        prof = committed_profile()
+        # instruction issue, and the fraction is formed in one clock domain, the kernel's own:
+        # a SIMD issues one full-rate vector instruction (v_mul_f32 / v_add_f32 / v_fma_f32) per
+        # 2 cycles, so `peak` = SIMDs x f / 2 with f the shader clock the timed launches ran at, read
+        # from the kernel's own cycle and 100 MHz counters; `achieved` = the launch's vector
+        # instructions (hardware counter of the committed profile of these very sources and this very
+        # traversal) over its HIP-event time.  frac = 2 x instructions / (SIMDs x kernel cycles).
+        # The device micro-probe, run now, shows the 2 cycles (and the lower clock a pure issue loop
+        # holds, which is why its clock stays out of `peak`).
+        prof, stale = committed_profile()
         probe = L.ValuProbe()
-        peak = None
-        if L.load().rt_probe_valu_issue(device_index, L.VALU_MIXES.index("mul_add"), 4, 2000, C.byref(probe)) == 0:
-            peak = probe.simds * probe.clock_mhz * 1e6 / probe.simd_cycles_per_inst / 1e9
+        have_probe = L.load().rt_probe_valu_issue(device_index, L.VALU_MIXES.index("mul_add"), 4, 2000, C.byref(probe)) == 0
+        simds = int(probe.simds) if have_probe else 1024
+        peak = simds * kernel_clock_mhz * 1e6 / 2.0 / 1e9 if kernel_clock_mhz else None
         insts = prof.get("valu_insts_per_launch")
         traffic = prof.get("traffic_bytes_per_launch")
         if insts and world > 1:
@@ -410,7 +486,12 @@ def main():
                        "rays_per_step": total_rays / args.steps},
             "roofline": {"bound": "valu_issue", "achieved": achieved, "peak": peak, "unit": "Ginst/s",
                          "frac": achieved / peak if achieved and peak else None,
+                         "profile_stale": stale,
                          "traffic": traffic,
+                         "kernel_clock_mhz": kernel_clock_mhz,
+                         "kernel_simd_cycles": (simds * kernel_ms * 1e-3 * kernel_clock_mhz * 1e6
+                                                if kernel_clock_mhz else None),
+                         "profile": prof.get("source"),
                          "kernel": "path_kernel_persistent" if args.pipeline else "path_kernel",
                          "kernel_ms": kernel_ms,
                          "valu_insts_per_launch": insts,
@@ -418,7 +499,8 @@ def main():
                          # probe's table) over its SIMD cycles; two bounds, see scripts/summarize_profile.py
                          "valu_pipe_time_frac_bounds": prof.get("valu_pipe_time_frac_bounds") if world == 1 else None,
                          "probe": {"class": "v_mul_f32 / v_add_f32", "waves_per_simd": 4,
-                                   "simd_cycles_per_inst": probe.simd_cycles_per_inst, "clock_mhz": probe.clock_mhz},
+                                   "simd_cycles_per_inst": probe.simd_cycles_per_inst,
+                                   "clock_mhz": probe.clock_mhz} if have_probe else None,
                          # the byte model of the reference's own data structures, and what reaches the
                          # fabric: the working set is cache-resident, HBM is not the bound
                          "hbm": {"algorithmic_bytes_per_launch": rank_bytes,

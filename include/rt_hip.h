@@ -145,9 +145,11 @@ int rt_render_frame(rt_ctx* ctx, const rt_cam_data* cam);
  * exactly as the event loop does (main.rs:147-148).  *cam is updated. */
 int rt_render_frames(rt_ctx* ctx, rt_cam_data* cam, uint32_t n);
 /* No counterpart in the reference.  rt_render_frames for callers that cannot allocate device
- * memory while they render (code under HIP graph capture, tight serving loops, harnesses that
- * forbid hipMalloc): this call allocates and frees nothing, on the device or through any
- * library.  The caller passes the frame buffers, both device memory of canvas_width *
+ * memory while they render (tight serving loops, harnesses that forbid hipMalloc): this call
+ * allocates and frees nothing, on the device or through any library.  It is not a call to put
+ * under HIP graph capture as it stands: the camera (frame number, frames_without_move) is a
+ * by-value kernel argument, so a replayed graph would render the same frame again, and the call
+ * records the timing events behind rt_last_render_ms.  The caller passes the frame buffers, both device memory of canvas_width *
  * canvas_height RGBA floats on the context's GPU: `acc_device` is binding 7 (read and written:
  * zero it before the first frame, lib.rs:57-60) and `present_device` binding 8 (written; NULL
  * skips the gamma pass).  The kernel's own work memory (queue heads, per-tile costs, tile
@@ -207,6 +209,13 @@ typedef struct rt_sched_stats {
 } rt_sched_stats;
 int rt_get_sched_stats(rt_ctx* ctx, rt_sched_stats* out);
 int rt_reset_stats(rt_ctx* ctx);
+/* The shader clock the persistent kernels ran at since the last rt_reset_stats (no counterpart in the
+ * reference; what an issue-bound roofline is priced in).  Every workgroup's first wave reads the
+ * shader-cycle counter and the constant 100 MHz counter when it starts and when it ends;
+ * *shader_cycles and *ticks_100mhz receive the sums of the differences over all workgroups of all
+ * launches, so shader_cycles / ticks_100mhz x 100 MHz is the clock, averaged over workgroups.  Both
+ * are 0 when only the plain kernel ran.  Synchronises the stream. */
+int rt_get_kernel_clock(rt_ctx* ctx, uint64_t* shader_cycles, uint64_t* ticks_100mhz);
 /* Device address of the accumulation buffer (canvas W*H*4 f32) of the current
  * canvas size, for callers that reduce it across GPUs themselves. */
 int rt_acc_device_ptr(rt_ctx* ctx, uint32_t width, uint32_t height, void** out);

@@ -146,6 +146,7 @@ SIGNATURES = {
     "rt_get_stats": (_i32, [_vp, _P(Stats)]),
     "rt_get_sched_stats": (_i32, [_vp, _P(SchedStats)]),
     "rt_reset_stats": (_i32, [_vp]),
+    "rt_get_kernel_clock": (_i32, [_vp, _P(C.c_uint64), _P(C.c_uint64)]),
     "rt_acc_device_ptr": (_i32, [_vp, _u32, _u32, _P(_vp)]),
     "rt_last_render_ms": (_i32, [_vp, _P(_f)]),
     "rt_bvh_params_default": (None, [_P(BvhParams)]),

@@ -203,6 +203,13 @@ class App:
                 "site_wait_cycles": list(s.site_wait_cycles),
                 "shade": [int(s.shade_iterations), int(s.shade_slots), int(s.shade_cycles)]}
 
+    def kernel_clock_mhz(self):
+        """Shader clock (MHz) the persistent kernels ran at since the last reset_stats, from the
+        kernels' own cycle and 100 MHz counters; None when no such launch has run."""
+        cyc, ticks = C.c_uint64(), C.c_uint64()
+        self._check(self._lib.rt_get_kernel_clock(self._ctx, C.byref(cyc), C.byref(ticks)))
+        return cyc.value / ticks.value * 100.0 if ticks.value else None
+
     def reset_stats(self):
         self._check(self._lib.rt_reset_stats(self._ctx))
 

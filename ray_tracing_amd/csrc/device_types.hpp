@@ -135,6 +135,13 @@ struct DevStats {
     unsigned long long site_wait[8];
     // the pooled kernel's SHADE steps: iterations, slots shaded, cycles
     unsigned long long shade_iters, shade_lanes, shade_cycles;
+    // the persistent kernels' own clock: every workgroup's first wave stamps the shader-cycle counter
+    // and the constant 100 MHz counter when it starts and when it ends and adds both differences
+    // here, so clk_cycles / clk_ticks x 100 MHz is the shader clock the launches ran at
+    unsigned long long clk_cycles, clk_ticks;
+    // pooled kernel: waves that left their loop with live ray slots because nothing was left to
+    // schedule (a scheduler fault: the launch's image is then incomplete)
+    unsigned long long pool_stalled;
 };
 
 // Work queues of the persistent kernel: 8 ranges of 64-pixel items (8x8 tiles),

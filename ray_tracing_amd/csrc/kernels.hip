@@ -1,6 +1,8 @@
 // HIP kernels for gfx950 (MI355X).  Compiled with -ffp-contract=off.
 #include <hip/hip_runtime.h>
 
+#include <mutex>
+
 #include "kernels.hpp"
 #include "trace_device.hpp"
 #include "trifilter.hpp"
@@ -61,6 +63,23 @@ __device__ __forceinline__ void flush_stats(const DevFrame& fr, bool count, uint
             atomicAdd(&fr.stats->internal_visits, n_internal);
             atomicAdd(&fr.stats->triangle_tests, n_tri);
         }
+    }
+}
+
+// The shader-cycle counter (s_memtime) and the constant 100 MHz counter (s_memrealtime), read
+// together.  A persistent wave lives as long as the launch, so one pair of stamps per workgroup
+// gives the clock the launch ran at without touching the steps.
+struct ClockStamp {
+    unsigned long long cycles, ticks;
+};
+__device__ __forceinline__ ClockStamp clock_stamp() {
+    return ClockStamp{__builtin_amdgcn_s_memtime(), __builtin_amdgcn_s_memrealtime()};
+}
+__device__ __forceinline__ void flush_clock(const DevFrame& fr, ClockStamp begin) {
+    const ClockStamp end = clock_stamp();
+    if (threadIdx.x == 0 && fr.stats) {
+        atomicAdd(&fr.stats->clk_cycles, end.cycles - begin.cycles);
+        atomicAdd(&fr.stats->clk_ticks, end.ticks - begin.ticks);
     }
 }
 
@@ -214,6 +233,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((COUNT |
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t* const stack = &s_stack[threadIdx.x];
     const unsigned long long lanes_below = (1ull << lane) - 1ull;
+    const ClockStamp clk_begin = clock_stamp();
 
     unsigned long long n_rays = 0, n_box = 0, n_internal = 0, n_tri = 0, n_paths = 0;
     unsigned long long sched_iters[3] = {0, 0, 0}, sched_lanes[3] = {0, 0, 0}, sched_cycles[3] = {0, 0, 0},
@@ -412,6 +432,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((COUNT |
         if (COUNT) sched_cycles[pick] += __builtin_readcyclecounter() - t_begin;
     }
     flush_stats(fr, COUNT, lane, n_rays, n_paths, n_box, n_internal, n_tri);
+    flush_clock(fr, clk_begin);
     if (COUNT && lane == 0 && fr.stats) {
         for (int k = 0; k < 3; ++k) {
             atomicAdd(&fr.stats->iters[k], sched_iters[k]);
@@ -469,6 +490,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((COUNT |
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint32_t* const stack = &s_stack[threadIdx.x];
     const unsigned long long lanes_below = (1ull << lane) - 1ull;
+    const ClockStamp clk_begin = clock_stamp();
     uint32_t* const state = &s_state[wave * kWaveSlots];
     uint32_t* const deal = &s_tmp[threadIdx.x & ~63u];
     RayRecord* const pool = records + (size_t)(blockIdx.x * (kBlock / 64u) + wave) * kWaveSlots;
@@ -538,7 +560,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((COUNT |
         // a full batch is shaded at once; a partial one when lanes are out of rays to trace
         if (n_shadeable >= 64u || (n_shadeable != 0u && (w_best == 0 || (n_ready == 0u && n_idle >= 16u)))) pick = 3;
         else if (w_best == 0) {
-            if (++stalls > 1000u) break;
+            if (++stalls > 1000u) {
+                // live slots and nothing to schedule: must not happen.  The wave gives up rather than
+                // spin for ever, and says so: the host turns a non-zero count into an error.
+                if (lane == 0 && fr.stats) atomicAdd(&fr.stats->pool_stalled, 1ull);
+                break;
+            }
             continue;
         }
         if (COUNT) {
@@ -773,6 +800,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((COUNT |
         if (COUNT) sched_cycles[pick] += __builtin_readcyclecounter() - t_begin;
     }
     flush_stats(fr, COUNT, lane, n_rays, n_paths, n_box, n_internal, n_tri);
+    flush_clock(fr, clk_begin);
     if (COUNT && lane == 0 && fr.stats) {
         for (int k = 0; k < 3; ++k) {
             atomicAdd(&fr.stats->iters[k], sched_iters[k]);
@@ -964,11 +992,13 @@ struct ScratchHost {
     uint32_t order_sig[5] = {0, 0, 0, 0, 0};
 };
 ScratchHost g_scratch[kMaxDevices];
+std::mutex g_scratch_mutex;  // contexts may be created on one GPU from several threads
 
 }  // namespace
 
 hipError_t noalloc_scratch_init(int device) {
     if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
     if (g_scratch[device].ptr) return hipSuccess;
     void* p = nullptr;
     const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));  // `device` is current
@@ -979,7 +1009,9 @@ hipError_t noalloc_scratch_init(int device) {
 }
 
 bool noalloc_scratch_view(int device, NoAllocView* out) {
-    if (device < 0 || device >= kMaxDevices || !g_scratch[device].ptr) return false;
+    if (device < 0 || device >= kMaxDevices) return false;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch[device].ptr) return false;
     ScratchHost& h = g_scratch[device];
     out->head = h.ptr->head;
     out->cost = h.ptr->cost;

@@ -37,6 +37,7 @@ struct rt_ctx {
     uint32_t W = 0, H = 0;
     float* d_acc = nullptr;
     float* d_present = nullptr;
+    bool present_valid = false;  // d_present holds the image of the last render (RT_OPT_PRESENT was on for it)
     uint32_t* d_present8 = nullptr;  // the 8-bit image on the device, allocated on first use
     // rt_present_begin / rt_present_end: the copy of the 8-bit image to the host runs on a stream
     // of its own, so that it overlaps the next render
@@ -122,6 +123,7 @@ void free_frame(rt_ctx* c) {
     }
     free_dev(c->d_acc);
     free_dev(c->d_present);
+    c->present_valid = false;
     free_dev(c->d_present8);
     free_dev(c->d_hit_tri);
     free_dev(c->d_hit_inst);
@@ -357,6 +359,15 @@ int render(rt_ctx* c, const rt_cam_data& cam, uint32_t n_frames, const DevFrame*
     }
     RT_HIP(c, hipEventRecord(c->ev1, c->stream));
     c->timed = true;
+    if (own_buffers) c->present_valid = fr.present != nullptr;
+    return RT_OK;
+}
+
+// The pooled kernel's waves record it when they give up with live ray slots; the image is then incomplete.
+int check_pool(rt_ctx* c, const DevStats& s) {
+    if (s.pool_stalled != 0)
+        return fail(c, RT_ERR_HIP, "pooled kernel: " + std::to_string(s.pool_stalled) +
+                                       " wave(s) stopped with unfinished pixels (scheduler fault); the image is incomplete");
     return RT_OK;
 }
 
@@ -421,9 +432,14 @@ const char* rt_last_error(const rt_ctx* c) { return c ? c->err.c_str() : g_creat
 
 int rt_set_stream(rt_ctx* c, void* hip_stream) {
     if (!c) return RT_ERR_INVALID;
-    // launches on the old stream still use the queue, cost and order buffers the next launch reuses
+    // launches on the old stream still use the queue, cost and order buffers the next launch reuses;
+    // a caller that has already destroyed the old stream has waited for them itself
     RT_HIP(c, hipSetDevice(c->device));
-    RT_HIP(c, hipStreamSynchronize(c->stream));
+    const hipError_t e = hipStreamSynchronize(c->stream);
+    if (e == hipErrorInvalidHandle || e == hipErrorContextIsDestroyed || e == hipErrorInvalidResourceHandle)
+        (void)hipGetLastError();
+    else if (e != hipSuccess)
+        return fail(c, RT_ERR_HIP, std::string("hipStreamSynchronize(old stream): ") + hipGetErrorString(e));
     c->stream = static_cast<hipStream_t>(hip_stream);
     return RT_OK;
 }
@@ -437,7 +453,10 @@ int rt_set_option(rt_ctx* c, int option, int64_t value) {
             return RT_OK;
         case RT_OPT_PROBE_HITS: c->probe_hits = value != 0; return RT_OK;
         case RT_OPT_COUNTERS: c->counters = value != 0; return RT_OK;
-        case RT_OPT_PRESENT: c->present = value != 0; return RT_OK;
+        case RT_OPT_PRESENT:
+            c->present = value != 0;
+            if (!c->present) c->present_valid = false;  // nothing keeps binding 8 in step with binding 7 from here on
+            return RT_OK;
         case RT_OPT_FRAME_STRIDE:
             if (value < 1 || value > 0x7FFFFFFF) return fail(c, RT_ERR_INVALID, "frame stride must be >= 1");
             c->frame_stride = (uint32_t)value;
@@ -647,16 +666,23 @@ static int read_back(rt_ctx* c, void* dst, const void* src, size_t bytes, size_t
     return RT_OK;
 }
 
-int rt_read_acc(rt_ctx* c, float* rgba, size_t n) { return read_back(c, rgba, c ? c->d_acc : nullptr, n * 16, n, "acc"); }
+int rt_read_acc(rt_ctx* c, float* rgba, size_t n) {
+    int rc = read_back(c, rgba, c ? c->d_acc : nullptr, n * 16, n, "acc");
+    if (rc != RT_OK || c->pipeline != 2) return rc;
+    DevStats s;
+    RT_HIP(c, hipMemcpy(&s, c->d_stats, sizeof s, hipMemcpyDeviceToHost));
+    return check_pool(c, s);
+}
 
 int rt_read_present(rt_ctx* c, float* rgba, size_t n) {
-    return read_back(c, rgba, c ? c->d_present : nullptr, n * 16, n, "present");
+    return read_back(c, rgba, (c && c->present_valid) ? c->d_present : nullptr, n * 16, n, "present");
 }
 
 // Binding 8 quantised into d_present8, enqueued on the render stream (after any copy that still
 // reads the buffer).
 static int quantise_present(rt_ctx* c) {
-    if (!c->d_present) return fail(c, RT_ERR_INVALID, "present was never produced (option off or nothing rendered)");
+    if (!c->d_present || !c->present_valid)
+        return fail(c, RT_ERR_INVALID, "present was never produced (option off or nothing rendered)");
     RT_HIP(c, hipSetDevice(c->device));
     const size_t n = (size_t)c->W * c->H;
     if (!c->d_present8) RT_HIP(c, hipMalloc(&c->d_present8, n * 4));
@@ -745,7 +771,7 @@ int rt_get_stats(rt_ctx* c, rt_stats* out) {
     out->internal_visits = s.internal_visits;
     out->triangle_tests = s.triangle_tests;
     out->paths = s.paths;
-    return RT_OK;
+    return check_pool(c, s);
 }
 
 int rt_get_sched_stats(rt_ctx* c, rt_sched_stats* out) {
@@ -764,6 +790,17 @@ int rt_get_sched_stats(rt_ctx* c, rt_sched_stats* out) {
     out->shade_iterations = s.shade_iters;
     out->shade_slots = s.shade_lanes;
     out->shade_cycles = s.shade_cycles;
+    return RT_OK;
+}
+
+int rt_get_kernel_clock(rt_ctx* c, uint64_t* shader_cycles, uint64_t* ticks_100mhz) {
+    if (!c || !shader_cycles || !ticks_100mhz) return RT_ERR_INVALID;
+    DevStats s;
+    RT_HIP(c, hipSetDevice(c->device));
+    RT_HIP(c, hipMemcpyAsync(&s, c->d_stats, sizeof s, hipMemcpyDeviceToHost, c->stream));
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    *shader_cycles = s.clk_cycles;
+    *ticks_100mhz = s.clk_ticks;
     return RT_OK;
 }
 

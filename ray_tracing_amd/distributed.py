@@ -33,7 +33,8 @@ def strip_rows(height, strip_h, rank, world):
 def gather_strips(local_image, strip_h, group=None, dst=0):
     """local_image: (H, W, C) tensor in which only this rank's rows are meaningful.
     Returns the assembled (H, W, C) image on rank `dst` (None elsewhere).  The
-    exchange is a gather of each rank's own rows, padded to a common length."""
+    exchange is one gather of each rank's own rows, padded to a common length: only
+    `dst` receives anything (1/world of the image from every other rank)."""
     import torch
     import torch.distributed as dist
 
@@ -48,8 +49,10 @@ def gather_strips(local_image, strip_h, group=None, dst=0):
     n_max = max(len(strip_rows(h, strip_h, r, world)) for r in range(world))
     send = torch.zeros((n_max,) + tuple(local_image.shape[1:]), dtype=local_image.dtype, device=local_image.device)
     send[: len(mine)] = local_image[mine]
-    out = [torch.empty_like(send) for _ in range(world)]
-    dist.all_gather(out, send, group=group)
+    out = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
+    if send.is_cuda and dist.get_backend(group) == "gloo":
+        torch.cuda.current_stream(send.device).synchronize()  # gloo copies from a thread of its own
+    dist.gather(send, out, dst=dst, group=group)
     if rank != dst:
         return None
     full = torch.empty_like(local_image)
@@ -59,9 +62,11 @@ def gather_strips(local_image, strip_h, group=None, dst=0):
     return full
 
 
-def reduce_samples(acc, group=None):
-    """Sum the per-rank accumulation buffers in place on every rank (sample mode):
-    one all-reduce of 4*W*H floats (1080p: 33 MB, 4K: 133 MB).  The collective is ordered after the
+def reduce_samples(acc, group=None, dst=None):
+    """Sum the per-rank accumulation buffers in place (sample mode): one collective over
+    4*W*H floats (1080p: 33 MB, 4K: 133 MB) -- a reduce to rank `dst` when only that rank
+    needs the image (the others' buffers are then left as they were), an all-reduce when
+    `dst` is None.  The collective is ordered after the
     work on torch's current stream of the tensor's device: render on that stream (App.create(...,
     stream=torch.cuda.current_stream().cuda_stream)) or synchronize the context first."""
     import torch.distributed as dist
@@ -73,7 +78,10 @@ def reduce_samples(acc, group=None):
             # returned.  RCCL needs no such wait: its kernel is ordered after the stream's work.
             import torch
             torch.cuda.current_stream(acc.device).synchronize()
-        dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=group)
+        if dst is None:
+            dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=group)
+        else:
+            dist.reduce(acc, dst=dst, op=dist.ReduceOp.SUM, group=group)
     return acc
 
 

@@ -10,6 +10,9 @@ import os
 import shutil
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import profiled_source_hash  # noqa: E402
+
 tag = sys.argv[1]
 src = os.path.join("gpurun_out", tag)
 os.makedirs("profiles", exist_ok=True)
@@ -113,6 +116,12 @@ if "bench_line_under_trace" in out and "l2_fabric_read_bytes" in d:
                "rays_per_launch": line["config"]["rays_per_step"],
                "simd_cycles_per_launch": d.get("simd_cycles"),
                "valu_pipe_time_frac_bounds": [d.get("valu_pipe_time_frac_low"), d.get("valu_pipe_time_frac_high")],
+               "valu_issue_floor_frac": d.get("valu_issue_floor_frac"),
+               # what the counters are valid for: these sources (hash of the kernel, builder and layout
+               # sources at the time of the run) and this traversal (the reference's debug counters of a launch)
+               "source_hash": profiled_source_hash(),
+               "counters_per_launch": {k: line["roofline"]["counters_per_launch"][k]
+                                       for k in ("rays", "box_tests", "internal_visits", "triangle_tests", "paths")},
                "source": f"profiles/{tag}_summary.json"}
     json.dump(traffic, open(os.path.join("profiles", "counters_bench.json"), "w"), indent=1)
 path = os.path.join("profiles", f"{tag}_summary.json")
