@@ -212,6 +212,13 @@ enum : uint32_t { CT_NEW_PIXEL = 0, CT_NEW_PATH = 1, CT_START_SEGMENT = 2, CT_NE
 typedef const __attribute__((address_space(4))) DevInstance* ConstInstance;
 constexpr uint32_t kNoItem = 0xFFFFFFFFu;
 
+// A yes/no per lane held as a 64-bit mask in scalar registers: lanes_where() is what a vector
+// comparison writes anyway, lane_of() hands a mask back as a per-lane condition (for a select, a
+// store, a branch) without an instruction, and everything in between is scalar arithmetic.
+typedef unsigned long long lmask;
+__device__ __forceinline__ lmask lanes_where(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+__device__ __forceinline__ bool lane_of(lmask m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
+
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 
@@ -224,9 +231,15 @@ __device__ __forceinline__ f2 vmax(f2 a, f2 b) { return __builtin_elementwise_ma
 // BIG: items are named by record number instead of byte offset (arenas of 4 GiB and more); the
 // address of an item then takes 64-bit arithmetic, two or three more instructions per fetch.
 template <int STACK_N, bool COUNT, bool BIG>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((COUNT || STACK_N > 32) ? 1 : 4))) void path_kernel_persistent(DevScene sc, DevCam cam, DevRows rows, DevFrame fr,
+#ifndef RT_EXP_WAVES
+#define RT_EXP_WAVES 4
+#endif
+#ifndef RT_EXP_STACK
+#define RT_EXP_STACK 32
+#endif
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((COUNT || STACK_N > 32) ? 1 : RT_EXP_WAVES))) void path_kernel_persistent(DevScene sc, DevCam cam, DevRows rows, DevFrame fr,
                                                                  DevQueue q, uint32_t n_frames) {
-    __shared__ uint32_t s_stack[STACK_N * kBlock];
+    __shared__ uint32_t s_stack[(STACK_N == 32 ? RT_EXP_STACK : STACK_N) * kBlock];
     __shared__ uint32_t s_tmp[kBlock];  // 64 words per wave: who works for whom in a LEAF step
     __shared__ unsigned long long s_best[kBlock];  // per lane: what an owner keeps of a LEAF step's results
 
@@ -235,7 +248,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((COUNT |
     const unsigned long long lanes_below = (1ull << lane) - 1ull;
     const ClockStamp clk_begin = clock_stamp();
 
-    unsigned long long n_rays = 0, n_box = 0, n_internal = 0, n_tri = 0, n_paths = 0;
+    // per lane, summed over the wave at the end.  Rays and paths of ONE lane in ONE launch are counted in
+    // 32 bits (a lane traces a few hundred thousand rays a second: 2^32 of them would be a launch of
+    // more than an hour); the sums are 64-bit.
+    uint32_t n_rays = 0, n_paths = 0;
+    unsigned long long n_box = 0, n_internal = 0, n_tri = 0;
     unsigned long long sched_iters[3] = {0, 0, 0}, sched_lanes[3] = {0, 0, 0}, sched_cycles[3] = {0, 0, 0},
                        sched_wait[3] = {0, 0, 0};  // wave-uniform
     unsigned long long site_wait[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // wave-uniform, profile only
@@ -279,7 +296,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((COUNT |
     // (origin, direction) pairs per axis, the reciprocals of the direction
     f2 dpx = {0.0f, 0.0f}, dpy = {0.0f, 0.0f}, dpz = {0.0f, 1.0f};
     float rcx = 1.0f, rcy = 1.0f, rcz = 1.0f;
-    bool rcp_ok = false;
+    lmask m_rcp_ok = 0ull;  // wave-uniform: the lanes whose ray is in the operand range of the cached-reciprocal division
     bool cull = false;
     f4 it0 = {0.0f, 0.0f, 0.0f, 0.0f}, it1 = it0, it2 = it0, it3 = it0;  // the pending item
     uint32_t cur = 0;  // ST_DESC / ST_POP: (node index << 1) | child slot;  ST_LEAF: triangle index
@@ -288,13 +305,17 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((COUNT |
     // Wave-uniform condition: lanes that have run out of pixels stay in the loop, inert, until
     // the whole wave is done, so that the cross-lane operations of the LEAF step always see all
     // 64 lanes.
-    while (__ballot(phase != ST_DEAD) != 0ull) {
+    for (;;) {
         uint32_t next_off = kNoItem;
         const unsigned long long t_begin = COUNT ? __builtin_readcyclecounter() : 0ull;
-        // wave-uniform choice of the one kind of step this iteration runs
-        const int w_ctl = __popcll(__ballot(phase == ST_CONTROL)) * q.w_ctl;
-        const int w_box = __popcll(__ballot(phase == ST_DESC || phase == ST_POP)) * q.w_box;
-        const int w_leaf = __popcll(__ballot(phase == ST_LEAF)) * q.w_leaf;
+        // wave-uniform choice of the one kind of step this iteration runs; a wave in which no lane waits
+        // for any kind (every lane is out of pixels) is done
+        const lmask m_ctl = lanes_where(phase == ST_CONTROL), m_leaf_wait = lanes_where(phase == ST_LEAF);
+        const lmask m_box_wait = lanes_where(phase == ST_DESC) | lanes_where(phase == ST_POP);
+        if ((m_ctl | m_leaf_wait | m_box_wait) == 0ull) break;
+        const int w_ctl = __popcll(m_ctl) * q.w_ctl;
+        const int w_box = __popcll(m_box_wait) * q.w_box;
+        const int w_leaf = __popcll(m_leaf_wait) * q.w_leaf;
         int pick = 1, w_best = w_box;
         if (w_leaf > w_best) pick = 2, w_best = w_leaf;
         if (w_ctl > w_best) pick = 0;
@@ -537,7 +558,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((COUNT |
     record_new(rec);
     f2 dpx = {0.0f, 0.0f}, dpy = {0.0f, 0.0f}, dpz = {0.0f, 1.0f};
     float rcx = 1.0f, rcy = 1.0f, rcz = 1.0f;
-    bool rcp_ok = false;
+    lmask m_rcp_ok = 0ull;  // wave-uniform: the lanes whose ray is in the operand range of the cached-reciprocal division
     bool cull = false;
     f4 it0 = {0.0f, 0.0f, 0.0f, 0.0f}, it1 = it0, it2 = it0, it3 = it0;  // the pending item
     uint32_t cur = 0;  // ST_DESC / ST_POP: (node index << 1) | child slot;  ST_LEAF: triangle index

@@ -37,7 +37,7 @@ struct rt_ctx {
     uint32_t W = 0, H = 0;
     float* d_acc = nullptr;
     float* d_present = nullptr;
-    bool present_valid = false;  // d_present holds the image of the last render (RT_OPT_PRESENT was on for it)
+    bool present_valid = false;  // d_present is in step with the accumulator: zeroed with it, or written by the last render
     uint32_t* d_present8 = nullptr;  // the 8-bit image on the device, allocated on first use
     // rt_present_begin / rt_present_end: the copy of the 8-bit image to the host runs on a stream
     // of its own, so that it overlaps the next render
@@ -146,6 +146,7 @@ int ensure_frame(rt_ctx* c, uint32_t W, uint32_t H) {
         RT_HIP(c, hipMemsetAsync(c->d_present, 0, n * 16, c->stream));
         c->W = W;
         c->H = H;
+        c->present_valid = true;  // a fresh canvas: nothing accumulated, nothing shown
     }
     if (c->probe_hits && !c->d_hit_tri) {
         RT_HIP(c, hipMalloc(&c->d_hit_tri, n * 4));
@@ -453,10 +454,7 @@ int rt_set_option(rt_ctx* c, int option, int64_t value) {
             return RT_OK;
         case RT_OPT_PROBE_HITS: c->probe_hits = value != 0; return RT_OK;
         case RT_OPT_COUNTERS: c->counters = value != 0; return RT_OK;
-        case RT_OPT_PRESENT:
-            c->present = value != 0;
-            if (!c->present) c->present_valid = false;  // nothing keeps binding 8 in step with binding 7 from here on
-            return RT_OK;
+        case RT_OPT_PRESENT: c->present = value != 0; return RT_OK;  // a render without it leaves binding 8 stale
         case RT_OPT_FRAME_STRIDE:
             if (value < 1 || value > 0x7FFFFFFF) return fail(c, RT_ERR_INVALID, "frame stride must be >= 1");
             c->frame_stride = (uint32_t)value;

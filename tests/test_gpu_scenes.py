@@ -801,6 +801,16 @@ def test_eight_bit_present_is_the_float_image_quantised_like_the_png_writer():
         f = app.read_present()
         b = app.read_present_rgba8()
         again = app.read_present_rgba8()
+        # a render with the gamma pass switched off leaves binding 8 behind the accumulator: reading it
+        # is refused, in every form, until a render with the pass on has brought it up to date
+        app.set_option(L.RT_OPT_PRESENT, 0)
+        app.render_frames(1)
+        for read in (app.read_present, app.read_present_rgba8, app.present_begin):
+            with pytest.raises(L.RtError):
+                read()
+        app.set_option(L.RT_OPT_PRESENT, 1)
+        app.render_frames(1)
+        assert app.read_present_rgba8().shape == (127, 333, 4)
     want = np.where(f > 0, np.minimum(np.rint(np.minimum(f, F(1.0)) * F(255.0)), 255), 0).astype(np.uint8)
     assert b.shape == (127, 333, 4) and np.array_equal(b, want) and np.array_equal(again, b)
     assert b[..., :3].max() == 255 and 0 < b[..., :3].mean() < 255 and (b[..., 3] == 255).all()
