@@ -3,9 +3,12 @@
 // render-and-advance turn (main.rs:129-149) run `frames` times, the image written as a PNG
 // instead of being copied to a swapchain.  Uses nothing but include/rt_hip.h.
 //
-//   render_default <resources dir> <out.png> [frames=64] [width=1280] [height=720] [acc.bin]
+//   render_default <resources dir> <out.png> [frames=64] [width=1280] [height=720] [acc.bin] [--gpus N]
 //
 // With a sixth argument the raw accumulator (binding 7, RGBA32F) is written there as well.
+// With --gpus N the event loop owns a group of N contexts instead of one (rt_group_*): the canvas is
+// dealt to them in strips and assembled on the first GPU, the image is the same bit for bit.  A box
+// with fewer than N GPUs names its GPUs more than once.
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -46,6 +49,14 @@ rt_affine3a srt(float sx, float sy, float sz, int axis, float angle, float tx, f
 }  // namespace
 
 int main(int argc, char** argv) {
+    unsigned gpus = 1;
+    for (int i = 1; i + 1 < argc; ++i)
+        if (std::strcmp(argv[i], "--gpus") == 0) {
+            gpus = (unsigned)std::atoi(argv[i + 1]);
+            for (int k = i; k + 2 < argc; ++k) argv[k] = argv[k + 2];
+            argc -= 2;
+            break;
+        }
     if (argc < 3) {
         std::fprintf(stderr, "usage: %s <resources dir> <out.png> [frames] [width] [height] [acc.bin]\n", argv[0]);
         return 2;
@@ -93,8 +104,28 @@ int main(int argc, char** argv) {
     std::printf("merged: %zu vertices, %zu triangles, %zu BVH nodes\n", nv, nt, nb);  // main.rs:68-73
 
     rt_ctx* ctx = nullptr;
-    check(nullptr, rt_create(0, &ctx), "rt_create");
-    check(ctx, rt_upload_scene_from_builder(ctx, sb), "rt_upload_scene_from_builder");
+    rt_group* group = nullptr;
+    auto gcheck = [&](int rc, const char* what) {
+        if (rc == RT_OK) return;
+        std::fprintf(stderr, "%s failed (%d): %s\n", what, rc, rt_group_last_error(group));
+        std::exit(1);
+    };
+    if (gpus > 1) {
+        int n_dev = 0;
+        if (rt_device_count(&n_dev) != RT_OK || n_dev < 1) {
+            std::fprintf(stderr, "no GPU\n");
+            return 1;
+        }
+        std::vector<int> devices(gpus);
+        for (unsigned i = 0; i < gpus; ++i) devices[i] = (int)(i % (unsigned)n_dev);
+        gcheck(rt_group_create(devices.data(), devices.size(), &group), "rt_group_create");
+        gcheck(rt_group_upload_scene_from_builder(group, sb), "rt_group_upload_scene_from_builder");
+        ctx = rt_group_context(group, 0);  // holds the assembled image
+        std::printf("group of %zu contexts on %d GPU(s)\n", rt_group_size(group), n_dev);
+    } else {
+        check(nullptr, rt_create(0, &ctx), "rt_create");
+        check(ctx, rt_upload_scene_from_builder(ctx, sb), "rt_upload_scene_from_builder");
+    }
     rt_scene_builder_free(sb);
 
     // the event loop's turn, main.rs:129-149: render, then frame += 1, frames_without_move += 1.
@@ -106,7 +137,8 @@ int main(int argc, char** argv) {
     size_t shown_pixels = 0;
     unsigned long long checksum = 0;
     for (unsigned f = 0; f < frames; ++f) {
-        check(ctx, rt_render_frames(ctx, &cam, 1), "rt_render_frames");
+        if (group) gcheck(rt_group_render_frames(group, &cam, 1, RT_GROUP_TILES), "rt_group_render_frames");
+        else check(ctx, rt_render_frames(ctx, &cam, 1), "rt_render_frames");
         if (f > 0) {
             check(ctx, rt_present_end(ctx, &shown, &shown_pixels), "rt_present_end");  // frame f - 1, "blitted"
             checksum += shown[0] + shown[4 * (shown_pixels / 2)];
@@ -131,6 +163,7 @@ int main(int argc, char** argv) {
         std::ofstream out(argv[6], std::ios::binary);
         out.write(reinterpret_cast<const char*>(image.data()), (std::streamsize)(image.size() * sizeof(float)));
     }
-    rt_destroy(ctx);
+    if (group) rt_group_destroy(group);
+    else rt_destroy(ctx);
     return 0;
 }

@@ -101,6 +101,9 @@ enum {
 };
 
 /* ---- lifecycle: vulkan::App::create / App::destroy (vulkan.rs:124-168, 374) ---- */
+/* How many GPUs rt_create can name (what the reference learns from enumerate_physical_devices,
+ * vulkan.rs:124-168). */
+int rt_device_count(int* n);
 int rt_create(int device, rt_ctx** out);
 void rt_destroy(rt_ctx* ctx);
 /* Message of the last failure on this context (ctx == NULL: last failure of
@@ -223,10 +226,65 @@ int rt_acc_device_ptr(rt_ctx* ctx, uint32_t width, uint32_t height, void** out);
  * measured with HIP events on the context's stream (synchronises). */
 int rt_last_render_ms(rt_ctx* ctx, float* ms);
 
+/* ============ several GPUs of one node as one renderer (no counterpart in the reference) ============
+ * The reference drives ONE App on one GPU (program/src/main.rs:129-149, vulkan.rs:124-236).  A pixel
+ * sample depends on the scene and on its own accumulator element only (shader/src/lib.rs:57-69), so
+ * the work shards with nothing exchanged while it is done: the scene is replicated, a group holds
+ * one context per entry of `devices` (the same GPU may be named more than once: a rehearsal on a
+ * box with fewer GPUs), each with a stream and a host thread of its own, and a render call returns
+ * when every context's work is enqueued.  The assembled image lives on the FIRST context's GPU.
+ *   RT_GROUP_TILES    the canvas is dealt to the contexts in interleaved strips of 8 rows
+ *                     (rt_set_rows); each renders all n frames of its strips, then its strips are
+ *                     copied device to device into the first context's binding 7.  Seeds depend on
+ *                     absolute pixel coordinates, so the image is, bit for bit, the one context's.
+ *   RT_GROUP_SAMPLES  every context renders the whole canvas for the samples whose running index is
+ *                     congruent to its rank (frame numbers keep their meaning: sample k of the
+ *                     call uses frame cam->frame + k) with RT_OPT_SEED_MODE 1 -- the reference's
+ *                     seed chains a pixel's samples through its accumulator, independent samples
+ *                     cannot -- then the accumulators are copied to the first GPU and added there
+ *                     IN RANK ORDER, ((a0 + a1) + a2) + ...: one definite value, comparable with
+ *                     the reference's sequence only statistically.  cam->frames_without_move < 0.5
+ *                     starts a new sum (shader/src/lib.rs:85-87), anything else continues it.
+ * Binding 8 is derived once, from the assembled accumulator, on the first GPU (RT_OPT_PRESENT of
+ * the first context).  At most 16 contexts (RT_ERR_LIMIT).  Calls on one group are not thread-safe.
+ * RT_OPT_FRAME_STRIDE / RT_OPT_SEED_MODE are the group's to set; the parity probes are per context. */
+typedef struct rt_scene_builder rt_scene_builder;
+typedef struct rt_group rt_group;
+#define RT_GROUP_TILES 0
+#define RT_GROUP_SAMPLES 1
+int rt_group_create(const int* devices, size_t n, rt_group** out);
+void rt_group_destroy(rt_group* group);
+/* Message of the last failure on this group (group == NULL: of rt_group_create on this thread). */
+const char* rt_group_last_error(const rt_group* group);
+size_t rt_group_size(const rt_group* group);
+/* Context i of the group (NULL when out of range): for per-context options, statistics and
+ * rt_present_begin / rt_present_end on context 0, which holds binding 8 of the assembled image. */
+rt_ctx* rt_group_context(rt_group* group, size_t i);
+/* rt_upload_scene / rt_upload_scene_from_builder / rt_set_materials / rt_update_instances /
+ * rt_set_option on every context, the uploads concurrently from the contexts' threads. */
+int rt_group_upload_scene(rt_group* group, const rt_scene_info* info,
+                          const rt_vertex* vertices, size_t n_vertices,
+                          const rt_tri* triangles, size_t n_triangles,
+                          const rt_object* objects, size_t n_objects,
+                          const rt_instance* instances, size_t n_instances,
+                          const rt_bvh* bvh, size_t n_bvh);
+int rt_group_upload_scene_from_builder(rt_group* group, rt_scene_builder* b);
+int rt_group_set_materials(rt_group* group, const rt_material* materials, size_t n);
+int rt_group_update_instances(rt_group* group, const rt_instance* instances, size_t n);
+int rt_group_set_option(rt_group* group, int option, int64_t value);
+/* n frames in the given mode; *cam advances as rt_render_frames advances it (main.rs:147-148). */
+int rt_group_render_frames(rt_group* group, rt_cam_data* cam, uint32_t n, int mode);
+int rt_group_synchronize(rt_group* group);
+/* The assembled binding 7 / binding 8 (n_pixels = canvas_width * canvas_height of the last call);
+ * each synchronises.  rt_group_acc_device_ptr: its address on the first context's GPU. */
+int rt_group_read_acc(rt_group* group, float* rgba, size_t n_pixels);
+int rt_group_read_present(rt_group* group, float* rgba, size_t n_pixels);
+int rt_group_acc_device_ptr(rt_group* group, void** out);
+
 /* ======================= host-side scene assembly ===========================
  * No GPU needed.  Mirrors program/src/modules/mod.rs and bvh.rs. */
 
-typedef struct rt_scene_builder rt_scene_builder;
+/* rt_scene_builder: declared above, with the group entry points */
 
 typedef struct rt_bvh_params {
     uint32_t root_leaf_max; /* bvh.rs:17      default 5  */

@@ -10,8 +10,8 @@ from ._lib import (CamData, Material, RtError, SceneInfo, RT_DEBUG_BVH_INTERSECT
                    RT_MAT_METAL, RT_MAT_NORMAL, RT_MAT_REFRACTIVE, RT_MAT_UV,
                    RT_OPT_COUNTERS, RT_OPT_FRAME_STRIDE, RT_OPT_PIPELINE, RT_OPT_PRESENT, RT_OPT_PROBE_HITS,
                    RT_OPT_SEED_MODE)
-from .app import App
+from .app import App, Group
 from .scene import (Scene, SceneBuilder, default_scene, make_cam, sphere_field_scene, terrain_scene)
 
-__all__ = ["App", "Scene", "SceneBuilder", "CamData", "Material", "SceneInfo", "RtError", "default_scene",
+__all__ = ["App", "Group", "Scene", "SceneBuilder", "CamData", "Material", "SceneInfo", "RtError", "default_scene",
            "make_cam", "sphere_field_scene", "terrain_scene"]

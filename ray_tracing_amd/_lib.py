@@ -104,6 +104,7 @@ RT_OPT_FRAME_STRIDE, RT_OPT_SEED_MODE = 5, 6
 RT_OPT_TILE_ORDER, RT_OPT_VOTE_WEIGHTS, RT_OPT_BLOCKS_PER_CU = 7, 8, 9
 RT_OPT_FORCE_BIG_OFFSETS, RT_OPT_FAST_DIV, RT_OPT_TILE_DEAL, RT_OPT_POOL_SLOTS = 10, 11, 12, 13
 RT_BVH_HOST, RT_BVH_DEVICE_LINEAR, RT_BVH_DEVICE_SAH = 0, 1, 2
+RT_GROUP_TILES, RT_GROUP_SAMPLES = 0, 1
 RT_MAT_GENERIC, RT_MAT_NORMAL, RT_MAT_EMISSIVE = 0, 1, 2
 RT_MAT_REFRACTIVE, RT_MAT_UV, RT_MAT_DIFFUSE, RT_MAT_METAL = 3, 4, 5, 6
 RT_DEBUG_NONE, RT_DEBUG_TRIANGLE_INTERSECTION, RT_DEBUG_BVH_INTERSECTION = 0, 1, 2
@@ -115,6 +116,7 @@ _P = C.POINTER
 SIGNATURES = {
     "rt_version": (C.c_char_p, []),
 
+    "rt_device_count": (_i32, [_P(C.c_int)]),
     "rt_create": (_i32, [_i32, _P(_vp)]),
     "rt_destroy": (None, [_vp]),
     "rt_last_error": (C.c_char_p, [_vp]),
@@ -149,6 +151,21 @@ SIGNATURES = {
     "rt_get_kernel_clock": (_i32, [_vp, _P(C.c_uint64), _P(C.c_uint64)]),
     "rt_acc_device_ptr": (_i32, [_vp, _u32, _u32, _P(_vp)]),
     "rt_last_render_ms": (_i32, [_vp, _P(_f)]),
+    "rt_group_create": (_i32, [_P(C.c_int), _sz, _P(_vp)]),
+    "rt_group_destroy": (None, [_vp]),
+    "rt_group_last_error": (C.c_char_p, [_vp]),
+    "rt_group_size": (_sz, [_vp]),
+    "rt_group_context": (_vp, [_vp, _sz]),
+    "rt_group_upload_scene": (_i32, [_vp, _P(SceneInfo), _vp, _sz, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _sz]),
+    "rt_group_upload_scene_from_builder": (_i32, [_vp, _vp]),
+    "rt_group_set_materials": (_i32, [_vp, _vp, _sz]),
+    "rt_group_update_instances": (_i32, [_vp, _vp, _sz]),
+    "rt_group_set_option": (_i32, [_vp, _i32, C.c_int64]),
+    "rt_group_render_frames": (_i32, [_vp, _P(CamData), _u32, _i32]),
+    "rt_group_synchronize": (_i32, [_vp]),
+    "rt_group_read_acc": (_i32, [_vp, _vp, _sz]),
+    "rt_group_read_present": (_i32, [_vp, _vp, _sz]),
+    "rt_group_acc_device_ptr": (_i32, [_vp, _P(_vp)]),
     "rt_bvh_params_default": (None, [_P(BvhParams)]),
     "rt_parse_obj": (_i32, [C.c_char_p, _sz, _vp, _P(_sz), _vp, _P(_sz)]),
     "rt_create_bvh": (_i32, [_vp, _sz, _vp, _sz, _P(BvhParams), _vp, _P(_sz)]),

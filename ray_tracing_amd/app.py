@@ -235,3 +235,89 @@ class App:
         ms = C.c_float()
         self._check(self._lib.rt_last_render_ms(self._ctx, C.byref(ms)))
         return float(ms.value)
+
+
+class Group:
+    """Several GPUs of one node as one renderer (rt_group_* of the C ABI): one context per entry of
+    `devices`, the scene replicated, the assembled image on the first GPU.  The reference has one
+    App on one GPU; a group is what its event loop (main.rs:129-149) would own instead."""
+
+    TILES, SAMPLES = L.RT_GROUP_TILES, L.RT_GROUP_SAMPLES
+
+    def __init__(self, cam_data, scene, devices):
+        self._lib = L.load()
+        self._g = C.c_void_p()
+        devs = (C.c_int * len(devices))(*devices)
+        rc = self._lib.rt_group_create(devs, len(devices), C.byref(self._g))
+        if rc != L.RT_OK:
+            msg = self._lib.rt_group_last_error(None).decode()
+            self._g = None
+            raise L.RtError(rc, msg)
+        self.cam_data = cam_data
+        self.devices = list(devices)
+        if scene is not None:
+            self.upload_scene(scene)
+
+    def _check(self, rc):
+        if rc != L.RT_OK:
+            raise L.RtError(rc, self._lib.rt_group_last_error(self._g).decode())
+
+    def destroy(self):
+        if getattr(self, "_g", None):
+            self._lib.rt_group_destroy(self._g)
+            self._g = None
+
+    __del__ = destroy
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.destroy()
+
+    def __len__(self):
+        return int(self._lib.rt_group_size(self._g))
+
+    def upload_scene(self, scene: Scene):
+        s = scene
+        self._check(self._lib.rt_group_upload_scene(
+            self._g, C.byref(s.info), _ptr(s.vertices), len(s.vertices), _ptr(s.triangles), len(s.triangles),
+            _ptr(s.objects), len(s.objects), _ptr(s.instances), len(s.instances), _ptr(s.bvh), len(s.bvh)))
+        if scene.materials is not None:
+            arr = (L.Material * len(scene.materials))(*scene.materials)
+            self._check(self._lib.rt_group_set_materials(self._g, arr, len(scene.materials)))
+
+    def set_option(self, option, value):
+        self._check(self._lib.rt_group_set_option(self._g, option, int(value)))
+
+    def context_option(self, i, option, value):
+        ctx = self._lib.rt_group_context(self._g, i)
+        if not ctx or self._lib.rt_set_option(ctx, option, int(value)) != L.RT_OK:
+            raise L.RtError(L.RT_ERR_INVALID, f"option {option} on context {i}")
+
+    def context_stats(self, i):
+        s = L.Stats()
+        if self._lib.rt_get_stats(self._lib.rt_group_context(self._g, i), C.byref(s)) != L.RT_OK:
+            raise L.RtError(L.RT_ERR_HIP, f"statistics of context {i}")
+        return {k: int(getattr(s, k)) for k, _ in L.Stats._fields_}
+
+    def render_frames(self, n, mode=L.RT_GROUP_TILES):
+        self._check(self._lib.rt_group_render_frames(self._g, C.byref(self.cam_data), n, mode))
+
+    def synchronize(self):
+        self._check(self._lib.rt_group_synchronize(self._g))
+
+    def _shape(self):
+        return int(self.cam_data.canvas_height), int(self.cam_data.canvas_width)
+
+    def read_acc(self):
+        h, w = self._shape()
+        out = np.empty((h, w, 4), np.float32)
+        self._check(self._lib.rt_group_read_acc(self._g, _ptr(out), h * w))
+        return out
+
+    def read_present(self):
+        h, w = self._shape()
+        out = np.empty((h, w, 4), np.float32)
+        self._check(self._lib.rt_group_read_present(self._g, _ptr(out), h * w))
+        return out

@@ -976,7 +976,12 @@ hipError_t launch_persistent_kernel(const DevScene& sc, const DevCam& cam, const
         if ((e2 = hipGetLastError()) != hipSuccess) return e2;
     }
     if (!fr.present) return hipSuccess;
+    return launch_present(cam, rows, fr, n_frames, stream);
+}
+
+hipError_t launch_present(const DevCam& cam, const DevRows& rows, const DevFrame& fr, uint32_t n_frames, hipStream_t stream) {
     const uint32_t n_pixels = cam.W * rows.local_rows;
+    if (n_pixels == 0 || n_frames == 0) return hipSuccess;
     // frames_without_move of the last frame, advanced the way the kernel advances it
     float fwm_last = cam.frames_without_move;
     for (uint32_t i = 1; i < n_frames; ++i) {
@@ -984,7 +989,28 @@ hipError_t launch_persistent_kernel(const DevScene& sc, const DevCam& cam, const
         if (next == fwm_last) break;  // the increments have stopped registering
         fwm_last = next;
     }
-    hipLaunchKernelGGL(present_kernel, dim3((n_pixels + kBlock - 1) / kBlock), block, 0, stream, cam, rows, fr, fwm_last);
+    hipLaunchKernelGGL(present_kernel, dim3((n_pixels + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, cam, rows, fr, fwm_last);
+    return hipGetLastError();
+}
+
+// out[i] = ((src[0][i] + src[1][i]) + src[2][i]) + ...: the per-GPU accumulators of a render split by
+// sample index, added in rank order (so that the sum is one definite value, the one a single process
+// adding the shares in that order gets).  `out` may be src[0].
+__global__ __launch_bounds__(kBlock) void sum_accumulators_kernel(float4* out, AccumulatorList list, uint32_t n) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    float4 a = reinterpret_cast<const float4*>(list.src[0])[i];
+    for (uint32_t k = 1; k < list.n; ++k) {
+        const float4 b = reinterpret_cast<const float4*>(list.src[k])[i];
+        a = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+    }
+    out[i] = a;
+}
+
+hipError_t launch_sum_accumulators(float* out, const AccumulatorList& list, uint32_t n_pixels, hipStream_t stream) {
+    if (n_pixels == 0 || list.n == 0) return hipSuccess;
+    hipLaunchKernelGGL(sum_accumulators_kernel, dim3((n_pixels + kBlock - 1) / kBlock), dim3(kBlock), 0, stream,
+                       reinterpret_cast<float4*>(out), list, n_pixels);
     return hipGetLastError();
 }
 

@@ -43,6 +43,18 @@ struct NoAllocView {
 hipError_t noalloc_scratch_init(int device);
 bool noalloc_scratch_view(int device, NoAllocView* out);
 
+// Binding 8 of this context's rows from binding 7 as it stands after `n_frames` frames that began at
+// `cam` (shader/src/lib.rs:85-108: the accumulator over the sample count, gamma 1/2.2).
+hipError_t launch_present(const DevCam& cam, const DevRows& rows, const DevFrame& fr, uint32_t n_frames, hipStream_t stream);
+
+// Accumulators of one canvas added in list order into `out` (which may be the first of them).
+constexpr uint32_t kMaxGroup = 16;
+struct AccumulatorList {
+    const float* src[kMaxGroup];
+    uint32_t n;
+};
+hipError_t launch_sum_accumulators(float* out, const AccumulatorList& list, uint32_t n_pixels, hipStream_t stream);
+
 // Binding 8 (RGBA32F) -> 8-bit RGBA, one word per pixel, R in the low byte.
 hipError_t launch_present_bytes(const float* present, uint32_t n_pixels, uint32_t* rgba8, hipStream_t stream);
 

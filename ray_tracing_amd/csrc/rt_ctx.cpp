@@ -13,76 +13,9 @@
 #include "gpu_layout.hpp"
 #include "host_scene.hpp"
 #include "kernels.hpp"
+#include "rt_ctx.hpp"
 
 using namespace rt;
-
-struct rt_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    std::string err;
-
-    // scene, resident in HBM
-    bool have_scene = false;
-    char* d_arena = nullptr;  // nodes | triangle test records | instances
-    size_t node_off = 0, tri_test_off = 0, inst_off = 0, arena_bytes = 0;
-    DevTri* d_tris = nullptr;
-    DevObject* d_objects = nullptr;
-    std::vector<DevInstance> h_instances;
-    std::vector<DevObject> h_objects;
-    uint32_t n_instances = 0;
-    uint32_t max_depth = 0;
-    bool fast_div = false;
-
-    // frame buffers, sized for the current canvas
-    uint32_t W = 0, H = 0;
-    float* d_acc = nullptr;
-    float* d_present = nullptr;
-    bool present_valid = false;  // d_present is in step with the accumulator: zeroed with it, or written by the last render
-    uint32_t* d_present8 = nullptr;  // the 8-bit image on the device, allocated on first use
-    // rt_present_begin / rt_present_end: the copy of the 8-bit image to the host runs on a stream
-    // of its own, so that it overlaps the next render
-    uint8_t* h_present8 = nullptr;  // pinned
-    hipStream_t copy_stream = nullptr;
-    hipEvent_t ev_quantised = nullptr, ev_copied = nullptr;
-    bool copy_pending = false;
-    uint32_t* d_hit_tri = nullptr;
-    uint32_t* d_hit_inst = nullptr;
-    uint32_t* d_hit_t = nullptr;
-    uint32_t* d_box = nullptr;
-    uint32_t* d_tritests = nullptr;
-    DevStats* d_stats = nullptr;
-    uint32_t* d_queue = nullptr;  // work-queue heads of the persistent kernel
-    void* d_pool = nullptr;       // ray slots of the pooled kernel
-    size_t pool_bytes = 0;
-    // cost-aware tile order: costs of the last launch, the order derived from them (two buffers:
-    // one read by a launch, the other written after it), and the canvas partition they belong to
-    uint32_t* d_tile_cost = nullptr;
-    uint32_t* d_tile_order[2] = {nullptr, nullptr};
-    uint32_t tile_capacity = 0;
-    int order_current = -1;  // which of d_tile_order holds a usable order; -1: none
-    uint32_t order_sig[5] = {0, 0, 0, 0, 0};
-    bool tile_order_enabled = true;
-    int n_cus = 0;
-    int vote_w[3] = {3, 2, 6};  // vote weights: control, box, triangle steps
-    uint32_t pool_slots = 0;     // RT_OPT_POOL_SLOTS
-    int tile_deal = -1;          // -1: by launch length; 0 / 1: RT_OPT_TILE_DEAL
-    int blocks_per_cu = 0;       // 0: as many as fit; RT_OPT_BLOCKS_PER_CU
-    bool force_big_offsets = false;
-    bool fast_div_enabled = true;
-    int per_cu_cache[2][2][2][2] = {};  // occupancy answers, 0 = not asked yet
-
-    // options
-    int pipeline = 1;
-    bool probe_hits = false;
-    bool counters = false;
-    bool present = true;
-    uint32_t frame_stride = 1;
-    uint32_t seed_mode = 0;
-    uint32_t strip_h = 0, rank = 0, world = 1;
-
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    bool timed = false;
-};
 
 namespace {
 
@@ -374,9 +307,51 @@ int check_pool(rt_ctx* c, const DevStats& s) {
 
 }  // namespace
 
+namespace rt {
+
+int ctx_fail(rt_ctx* c, int code, const std::string& msg) { return fail(c, code, msg); }
+
+int ctx_render(rt_ctx* c, const rt_cam_data& cam, uint32_t n_frames, bool present) {
+    RT_HIP(c, hipSetDevice(c->device));
+    const bool wanted = c->present;
+    c->present = wanted && present;
+    const int rc = render(c, cam, n_frames, nullptr, nullptr);
+    c->present = wanted;
+    return rc;
+}
+
+int ctx_present_whole_canvas(rt_ctx* c, const rt_cam_data& cam, uint32_t n_frames, const float* acc) {
+    RT_HIP(c, hipSetDevice(c->device));
+    int rc = ensure_frame(c, cam.canvas_width, cam.canvas_height);
+    if (rc != RT_OK) return rc;
+    const DevCam dc = make_cam(cam, c->frame_stride, c->seed_mode);
+    DevRows rows;
+    rows.strip_h = cam.canvas_height;
+    rows.rank = 0;
+    rows.world = 1;
+    rows.local_rows = cam.canvas_height;
+    DevFrame fr;
+    std::memset(&fr, 0, sizeof fr);
+    fr.acc = const_cast<float*>(acc ? acc : c->d_acc);  // read only by the pass
+    fr.present = c->d_present;
+    RT_HIP(c, launch_present(dc, rows, fr, n_frames, c->stream));
+    c->present_valid = n_frames != 0;
+    return RT_OK;
+}
+
+}  // namespace rt
+
 extern "C" {
 
 const char* rt_version(void) { return "ray_tracing_amd 0.1 (gfx950)"; }
+
+int rt_device_count(int* n) {
+    if (!n) return RT_ERR_INVALID;
+    *n = 0;
+    const hipError_t e = hipGetDeviceCount(n);
+    if (e != hipSuccess) return fail(nullptr, RT_ERR_HIP, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+    return RT_OK;
+}
 
 int rt_create(int device, rt_ctx** out) {
     if (!out) return fail(nullptr, RT_ERR_INVALID, "out is NULL");

@@ -34,3 +34,21 @@ def test_cpp_host_renders_the_start_up_scene_like_the_python_mirror(tmp_path):
     assert (got[..., 3] == frames).all() or got[..., :3].max() > 0
     data = png.read_bytes()
     assert data[:8] == b"\x89PNG\r\n\x1a\n" and len(data) > 1000
+
+
+def test_cpp_host_with_a_group_of_contexts_renders_the_same_image(tmp_path):
+    """`--gpus 3`: the event loop owns a group (three contexts on this box's one GPU) and presents from
+    the first context, which holds the assembled image: the same accumulator bit for bit."""
+    if not os.path.exists(EXE):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples")])
+    w, h, frames = 320, 180, 3
+    res = os.path.join(ROOT, "ray_tracing_amd", "resources")
+    accs = []
+    for extra in ([], ["--gpus", "3"]):
+        png, acc_file = tmp_path / f"out{len(extra)}.png", tmp_path / f"acc{len(extra)}.bin"
+        out = subprocess.run([EXE, res, str(png), str(frames), str(w), str(h), str(acc_file)] + extra, check=True,
+                             capture_output=True, text=True, timeout=120).stdout
+        assert ("group of 3 contexts" in out) == bool(extra)
+        accs.append(np.fromfile(acc_file, np.uint32))
+        assert png.read_bytes()[:8] == b"\x89PNG\r\n\x1a\n"
+    assert np.array_equal(accs[0], accs[1])
