@@ -97,7 +97,12 @@ enum {
      * frames, banded for longer ones. */
     RT_OPT_TILE_DEAL = 12,
     /* Pooled kernel (RT_OPT_PIPELINE 2): ray slots each wave keeps in flight, 64..192; 0 (default) = 192. */
-    RT_OPT_POOL_SLOTS = 13
+    RT_OPT_POOL_SLOTS = 13,
+    /* 1 (default) = the persistent kernels pass an instance by when the world-space ray clearly misses a
+     *     box stored with the instance, instead of moving the ray into the instance's space to find the
+     *     same thing out from the object's root box (trace.rs:76-95, hit.rs:76-86); 0 = always the
+     *     reference's way.  Same pixels and counters either way. */
+    RT_OPT_INSTANCE_CULL = 14
 };
 
 /* ---- lifecycle: vulkan::App::create / App::destroy (vulkan.rs:124-168, 374) ---- */
@@ -398,6 +403,13 @@ uint64_t rt_selftest_div_by_rcp(uint64_t n, uint64_t seed);
  * miss, and beyond the clamp or not).  Must return 0.  *n_clear receives the number
  * of cases that were called clear-cut. */
 uint64_t rt_selftest_slab_filter(uint64_t n, uint64_t seed, uint64_t* n_clear);
+/* Self-test of the cull above the instance list (RT_OPT_INSTANCE_CULL): draws n (instance transform,
+ * object root box, world ray, clamp) cases from `seed` -- rotated, unevenly scaled, far-translated
+ * instances; rays aimed at the rim of the box from any distance, axis-parallel rays, boxes behind the
+ * origin -- and returns how many cases the world-space test passed by although the reference's own
+ * arithmetic (ray into object space, slab test of the root box, clamp; trace.rs:88-94, 208-229,
+ * hit.rs:83) enters the instance.  Must return 0.  *n_passed_by receives the number passed by. */
+uint64_t rt_selftest_instance_cull(uint64_t n, uint64_t seed, uint64_t* n_passed_by);
 /* Self-test of the triangle test's shortcut: whether the plane hit point lies
  * inside the triangle is first read off three approximate edge functions and the
  * exact cross products are only evaluated when a sign is not clear-cut.  Draws n

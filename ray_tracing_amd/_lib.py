@@ -103,6 +103,7 @@ RT_OPT_PIPELINE, RT_OPT_PROBE_HITS, RT_OPT_COUNTERS, RT_OPT_PRESENT = 1, 2, 3, 4
 RT_OPT_FRAME_STRIDE, RT_OPT_SEED_MODE = 5, 6
 RT_OPT_TILE_ORDER, RT_OPT_VOTE_WEIGHTS, RT_OPT_BLOCKS_PER_CU = 7, 8, 9
 RT_OPT_FORCE_BIG_OFFSETS, RT_OPT_FAST_DIV, RT_OPT_TILE_DEAL, RT_OPT_POOL_SLOTS = 10, 11, 12, 13
+RT_OPT_INSTANCE_CULL = 14
 RT_BVH_HOST, RT_BVH_DEVICE_LINEAR, RT_BVH_DEVICE_SAH = 0, 1, 2
 RT_GROUP_TILES, RT_GROUP_SAMPLES = 0, 1
 RT_MAT_GENERIC, RT_MAT_NORMAL, RT_MAT_EMISSIVE = 0, 1, 2
@@ -189,6 +190,7 @@ SIGNATURES = {
     "rt_selftest_div_by_rcp": (C.c_uint64, [C.c_uint64, C.c_uint64]),
     "rt_selftest_slab_filter": (C.c_uint64, [C.c_uint64, C.c_uint64, _P(C.c_uint64)]),
     "rt_selftest_tri_filter": (C.c_uint64, [C.c_uint64, C.c_uint64, _P(C.c_uint64)]),
+    "rt_selftest_instance_cull": (C.c_uint64, [C.c_uint64, C.c_uint64, _P(C.c_uint64)]),
 }
 
 _lib = None

@@ -84,7 +84,13 @@ struct alignas(64) DevInstance {
     float specular;
     float specular_roughness;
     float roughness;
-    uint32_t pad2[10];
+    // A box in WORLD space that holds the object's root box with room to spare (instance_cull.hpp): a
+    // ray that clearly misses it is known to fail the reference's object-space test of the root box,
+    // so the instance walk can pass the instance by without moving the ray into its space.
+    // bound_ok = 0: no such box could be made (transform without a usable inverse, non-finite box).
+    float wlo[3], whi[3];
+    uint32_t bound_ok;
+    uint32_t pad2[3];
 };
 static_assert(sizeof(DevInstance) == 256, "four 64-byte lines");
 
@@ -123,6 +129,7 @@ struct DevScene {
     uint32_t node_unit, tri_test_unit;          // the same offsets in 64-byte records (any arena below 256 GiB)
     uint32_t n_instances;
     uint32_t fast_div;  // every box coordinate is 0 or has 2^-24 <= |b| <= 2^24 (see fastdiv.hpp)
+    uint32_t instance_cull;  // 1: the instance walk first tries DevInstance's world-space box
 };
 
 struct DevStats {

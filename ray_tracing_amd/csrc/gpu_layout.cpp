@@ -8,6 +8,7 @@
 #include "fastdiv.hpp"
 #include "host_math.hpp"
 #include "host_scene.hpp"
+#include "instance_cull.hpp"
 #include "trifilter.hpp"
 
 namespace rt {
@@ -96,6 +97,8 @@ void set_instance_transform(DevInstance& di, const rt_instance& inst, const std:
     pack_affine(inst.transform, di.fwd);
     di.object_id = inst.object_id;
     di.root = objects[inst.object_id].root;
+    const float lo[3] = {di.root.lox[0], di.root.loy[0], di.root.loz[0]}, hi[3] = {di.root.hix[0], di.root.hiy[0], di.root.hiz[0]};
+    di.bound_ok = instance_world_bound(di.inv, lo, hi, di.wlo, di.whi) ? 1u : 0u;
 }
 
 bool build_gpu_scene(const rt_scene_info& info, const rt_vertex* vertices, size_t n_vertices, const rt_tri* triangles,

@@ -3,6 +3,7 @@
 
 #include <mutex>
 
+#include "instance_cull.hpp"
 #include "kernels.hpp"
 #include "trace_device.hpp"
 #include "trifilter.hpp"

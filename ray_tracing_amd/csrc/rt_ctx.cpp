@@ -207,6 +207,7 @@ int render(rt_ctx* c, const rt_cam_data& cam, uint32_t n_frames, const DevFrame*
     sc.tri_test_unit = (uint32_t)(c->tri_test_off / 64);
     sc.n_instances = c->n_instances;
     sc.fast_div = (c->fast_div && c->fast_div_enabled) ? 1u : 0u;
+    sc.instance_cull = c->instance_cull ? 1u : 0u;
     // the persistent kernel names items by 32-bit byte offsets into the arena, or by 32-bit record
     // numbers (64-byte units) when the arena is 4 GiB or more (RT_OPT_FORCE_BIG_OFFSETS: always)
     const bool big = c->arena_bytes > 0xFFFFFFFFull || c->force_big_offsets;
@@ -457,6 +458,7 @@ int rt_set_option(rt_ctx* c, int option, int64_t value) {
             return RT_OK;
         case RT_OPT_FORCE_BIG_OFFSETS: c->force_big_offsets = value != 0; return RT_OK;
         case RT_OPT_FAST_DIV: c->fast_div_enabled = value != 0; return RT_OK;
+        case RT_OPT_INSTANCE_CULL: c->instance_cull = value != 0; return RT_OK;
         case RT_OPT_POOL_SLOTS:
             if (value != 0 && (value < 64 || value > 192)) return fail(c, RT_ERR_INVALID, "pool slots: 0 (all) or 64..192");
             c->pool_slots = (uint32_t)value;

@@ -64,6 +64,7 @@ struct rt_ctx {
     int blocks_per_cu = 0;       // 0: as many as fit; RT_OPT_BLOCKS_PER_CU
     bool force_big_offsets = false;
     bool fast_div_enabled = true;
+    bool instance_cull = true;   // RT_OPT_INSTANCE_CULL
     int per_cu_cache[2][2][2][2] = {};  // occupancy answers, 0 = not asked yet
 
     // options

@@ -8,6 +8,7 @@
 #include "../../include/rt_hip.h"
 #include "fastdiv.hpp"
 #include "host_math.hpp"
+#include "instance_cull.hpp"
 #include "host_scene.hpp"
 #include "trifilter.hpp"
 
@@ -267,6 +268,87 @@ uint64_t rt_selftest_div_by_rcp(uint64_t n, uint64_t seed) {
             ++bad;
         }
     }
+    return bad;
+}
+
+uint64_t rt_selftest_instance_cull(uint64_t n, uint64_t seed, uint64_t* n_passed_by) {
+    auto next = [&seed]() {
+        seed += 0x9E3779B97F4A7C15ull;
+        uint64_t z = seed;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        return z ^ (z >> 31);
+    };
+    auto unit = [&next]() { return float(next() >> 40) * (1.0f / 16777216.0f); };  // [0, 1)
+    auto sym = [&]() { return unit() * 2.0f - 1.0f; };
+    uint64_t bad = 0, passed = 0;
+    rt_affine3a xf;
+    float inv[12] = {0}, lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0}, wlo[3], whi[3];
+    rt_affine3a fwd_inv;
+    bool have = false;
+    for (uint64_t i = 0; i < n; ++i) {
+        if (i % 64 == 0) {
+            // an instance: rotation about a random axis, scales up to 1 : 8 apart, a translation that may dwarf
+            // the box, and an object box anywhere near the object's origin
+            float q[4] = {sym(), sym(), sym(), sym()};
+            const float ql = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+            if (!(ql > 1e-3f)) continue;
+            for (float& c : q) c /= ql;
+            const float base = std::ldexp(1.0f + unit(), int(next() % 16) - 8);
+            const V3 scale = v3(base * (1.0f + 7.0f * unit() * float(next() % 2)), base * (1.0f + 3.0f * unit() * float(next() % 2)),
+                                (next() % 8 == 0 ? -base : base));
+            const float far = std::ldexp(1.0f, int(next() % 14) - 2);
+            xf = affine_from_srt(scale, q, v3(sym() * far, sym() * far, sym() * far));
+            fwd_inv = affine_inverse(xf);  // what the kernels multiply with (trace.rs:87)
+            std::memcpy(inv + 0, fwd_inv.x_axis, 12);
+            std::memcpy(inv + 3, fwd_inv.y_axis, 12);
+            std::memcpy(inv + 6, fwd_inv.z_axis, 12);
+            std::memcpy(inv + 9, fwd_inv.translation, 12);
+            const float ext = std::ldexp(1.0f + unit(), int(next() % 10) - 5);
+            for (int k = 0; k < 3; ++k) {
+                const float c = sym() * ext * float(next() % 3);
+                lo[k] = c - ext * unit();
+                hi[k] = c + ext * unit() * (next() % 16 == 0 ? 0.0f : 1.0f);  // now and then flat
+            }
+            have = instance_world_bound(inv, lo, hi, wlo, whi);
+        }
+        if (!have) continue;
+        // a world ray: origin anywhere up to far away, aimed at a point on or just off the rim of the object
+        // box (mapped to world), or anywhere; now and then parallel to a world axis
+        const float reach = std::ldexp(1.0f, int(next() % 12));
+        V3 p = v3(sym() * reach, sym() * reach, sym() * reach);
+        V3 target_o = v3(next() % 2 ? lo[0] : hi[0], next() % 2 ? lo[1] : hi[1], lo[2] + (hi[2] - lo[2]) * unit());
+        const float off = std::ldexp(sym(), -int(next() % 24));  // from far off the rim down to rounding distance
+        target_o = target_o + v3(off * (hi[0] - lo[0] + 1e-3f), off * (hi[1] - lo[1] + 1e-3f), 0.0f);
+        V3 target_w = transform_point3(xf, target_o);
+        V3 d = (next() % 8 == 0) ? v3(sym(), sym(), sym()) : target_w - p;
+        if (next() % 16 == 0) d.x = 0.0f;
+        if (next() % 16 == 0) d.y = 0.0f;
+        if (!(dot(d, d) > 0.0f)) continue;
+        d = normalize(d);
+        if (next() % 8 == 0) d = -d;  // the box behind the origin
+        const float t_hi = (next() % 4 == 0) ? length(target_w - p) * (0.5f + unit()) : INFINITY;
+        // the cull
+        const float m_p = kCullEta * std::fmax(std::fmax(std::fabs(p.x), std::fabs(p.y)), std::fabs(p.z));
+        if (!instance_clearly_missed(wlo, whi, p.x, p.y, p.z, 1.0f / d.x, 1.0f / d.y, 1.0f / d.z, m_p, t_hi)) continue;
+        ++passed;
+        // the reference: ray into object space (trace.rs:88-91), slab test of the root box (trace.rs:208-229), hit.rs:83
+        const V3 np = transform_point3(fwd_inv, p), nd = transform_vector3(fwd_inv, d);
+        const float pp[3] = {np.x, np.y, np.z}, dd[3] = {nd.x, nd.y, nd.z};
+        float t_near = -INFINITY, t_far = INFINITY;
+        bool first = true;
+        for (int k = 0; k < 3; ++k) {
+            float a = (lo[k] - pp[k]) / dd[k], b = (hi[k] - pp[k]) / dd[k];
+            if (a > b) std::swap(a, b);
+            t_near = first ? a : std::fmax(t_near, a);  // f32::max: a NaN operand is ignored
+            t_far = first ? b : std::fmin(t_far, b);
+            first = false;
+        }
+        const float dist = (t_near < INFINITY && t_near < t_far && t_far > 0.0f) ? t_near : INFINITY;
+        const bool reference_leaves = dist == INFINITY || dist > t_hi;
+        if (!reference_leaves) ++bad;
+    }
+    if (n_passed_by) *n_passed_by = passed;
     return bad;
 }
 

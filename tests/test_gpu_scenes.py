@@ -231,6 +231,13 @@ def test_several_hundred_instances_of_small_meshes():
     for pipeline in (1, 0):
         g, ref = check_against_oracle(scene, cam, frames=2, materials=materials, pipeline=pipeline)
     assert len(np.unique(ref.hit_instance[ref.hit_triangle != 0xFFFFFFFF])) > 30
+    # the cull above the instance list (on by default, and so in the renders above) changes no word:
+    # the same frames with every instance taken the reference's way, on both persistent kernels
+    for pipeline in (1, 2):
+        off = gpu_render(scene, cam, 2, materials=materials, pipeline=pipeline, options=((L.RT_OPT_INSTANCE_CULL, 0),))
+        assert_bits_equal(off["acc"], g["acc"], "accumulator with the instance cull off")
+        assert_bits_equal(off["counters"][0], g["counters"][0], "box tests with the instance cull off")
+        assert off["stats"] == g["stats"]
 
 
 def test_hand_built_trees_with_edge_cases():

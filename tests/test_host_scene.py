@@ -377,3 +377,14 @@ def test_triangle_shortcut_never_decides_differently_when_it_calls_a_case_clear(
         clear = C.c_uint64(0)
         assert lib.rt_selftest_tri_filter(2_000_000, seed, C.byref(clear)) == 0
         assert 500_000 < clear.value < 1_900_000
+
+
+def test_instance_cull_never_passes_by_an_instance_the_reference_enters():
+    """The world-space test above the instance list (instance_cull.hpp) against the reference's own
+    arithmetic -- ray into object space, slab test of the root box, clamp (trace.rs:88-94, 208-229,
+    hit.rs:83) -- on rotated, unevenly scaled, far-translated instances with rays aimed at the rim of
+    the box: whatever it passes by, the reference leaves too; and it does pass a good share by."""
+    for seed in (1, 0xC0FFEE):
+        passed = C.c_uint64(0)
+        assert lib.rt_selftest_instance_cull(3_000_000, seed, C.byref(passed)) == 0
+        assert 500_000 < passed.value < 2_500_000
