@@ -78,6 +78,46 @@ def test_default_scene_vs_libm_trig(c1):
     assert frac_equal > 0.95, frac_equal
 
 
+@pytest.mark.parametrize("closed", [False, True])
+def test_terrain_scenes_vs_libm_trig(closed):
+    """The same link to a host libm's sin / cos off the default scene: the benchmark's scene in
+    miniature (terrain, glass cube, light; depth 10) and its closed-box form in which no path escapes
+    and every path that is not absorbed by the light draws eight scattered directions (depth 9).
+    One sample: primary hits bit-equal to the libm-trig oracle, pixels whose path drew no scattered
+    direction equal to 1e-4.  256 samples against a 4096-sample libm-trig oracle image: the GPU's
+    relative RMSE within 15 % of the libm-trig oracle's own 256 frames and below 1.6 / sqrt(256) of
+    the one-sample RMSE (the bounds test_gpu_multi.py states for the default scene)."""
+    from ray_tracing_amd import App, terrain_scene
+    w, h, n = 96, 54, 256
+    scene, cam = terrain_scene(w, h, n=48, depth=9 if closed else 10, closed_box=closed, light=True, threads=4, leaf_max=4)
+    g = gpu_render(scene, cam, 1, counters=False)
+    ref = O.OracleRenderer(scene, cam, trig=O.TRIG_LIBM, threads=16).render(1)
+    tri, inst, tb = g["hits"]
+    assert_bits_equal(tri, ref.hit_triangle, "triangle_id")
+    assert_bits_equal(inst, ref.hit_instance, "instance_id")
+    assert_bits_equal(tb, ref.hit_t_bits, "t bits")
+    direct = (ref.hit_triangle == 0xFFFFFFFF) | (ref.hit_instance == 2)  # sky (open scene only) or the light
+    assert direct.sum() > 50
+    np.testing.assert_allclose(g["acc"][direct], ref.acc[direct], rtol=1e-4, atol=0)
+
+    truth = O.OracleRenderer(scene, cam, trig=O.TRIG_LIBM, threads=16).render(4096).acc[..., :3] / np.float32(4096)
+    scale = float(truth.mean())
+    assert scale > 0.0
+
+    def rel_rmse(acc, spp):
+        d = acc[..., :3].astype(np.float64) / spp - truth.astype(np.float64)
+        return float(np.sqrt(np.mean(d * d))) / scale
+
+    with App.create(copy_cam(cam), scene) as app:
+        app.render_frames(1)
+        one = rel_rmse(app.read_acc(), 1)
+        app.render_frames(n - 1)
+        gpu = rel_rmse(app.read_acc(), n)
+    libm = rel_rmse(O.OracleRenderer(scene, cam, trig=O.TRIG_LIBM, threads=16).render(n).acc, n)
+    assert abs(libm - gpu) <= 0.15 * libm, (libm, gpu)
+    assert gpu <= 1.6 * one / np.sqrt(n), (one, gpu)
+
+
 @pytest.mark.parametrize("mode", [RT_DEBUG_TRIANGLE_INTERSECTION, RT_DEBUG_BVH_INTERSECTION])
 def test_debug_heat_maps(c1, mode):
     """The two heat-map modes of trace.rs:97-125."""
