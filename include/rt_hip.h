@@ -459,7 +459,12 @@ enum {
     RT_VALU_MIX_DPP = 16,        /* v_add_u32 with a DPP row shift (the wave scans) */
     RT_VALU_MIX_BFI = 17,        /* v_bfi_b32: a bitwise select, three vector operands */
     RT_VALU_MIX_AND_OR = 18,     /* v_and_or_b32 */
-    RT_VALU_MIX_COUNT = 19
+    /* not vector instructions: what a scalar instruction costs, alone and between vector ones
+     * (valu_insts then counts all instructions of the body, scalar ones included) */
+    RT_VALU_MIX_SALU = 19,       /* s_add_u32 */
+    RT_VALU_MIX_VALU_SALU = 20,  /* v_mul_f32 and s_add_u32 in turn */
+    RT_VALU_MIX_SLOW_SALU = 21,  /* v_cndmask_b32 and s_add_u32 in turn */
+    RT_VALU_MIX_COUNT = 22
 };
 typedef struct rt_valu_probe {
     uint64_t valu_insts;        /* vector instructions all waves issued inside their timed windows */

@@ -82,7 +82,8 @@ class ValuProbe(C.Structure):
 
 
 VALU_MIXES = ("fma", "mul_add", "pk_mul_add", "pk_fma", "min_max", "cndmask", "cmp", "int", "trans", "box_step",
-              "min3_max3", "cndmask_vcc", "cmp_vcc", "mov", "shift_cvt", "mul_lo", "dpp", "bfi", "and_or")
+              "min3_max3", "cndmask_vcc", "cmp_vcc", "mov", "shift_cvt", "mul_lo", "dpp", "bfi", "and_or", "salu",
+              "valu_salu", "slow_salu")
 
 
 class BvhParams(C.Structure):

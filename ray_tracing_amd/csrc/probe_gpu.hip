@@ -27,10 +27,37 @@ typedef float pf2 __attribute__((ext_vector_type(2)));
 #define RT_PK1(OP, k) asm volatile(OP " %0, %0, %1" : "+v"(p[k]) : "v"(pa))
 #define RT_PK2(OP, k) asm volatile(OP " %0, %0, %1, %2" : "+v"(p[k]) : "v"(pa), "v"(pb))
 
+#define RT_S1(k) asm volatile("s_add_u32 %0, %0, 1" : "+s"(sg[k]) : : "scc")
+
 template <int MIX>
 __device__ __forceinline__ void probe_body(float (&r)[16], pf2 (&p)[8], float a, float b, pf2 pa, pf2 pb,
-                                           unsigned long long& m0, unsigned long long& m1) {
-    if constexpr (MIX == RT_VALU_MIX_FMA) {
+                                           unsigned long long& m0, unsigned long long& m1, uint32_t (&sg)[8]) {
+    if constexpr (MIX == RT_VALU_MIX_SALU) {
+        // nothing but scalar instructions, eight independent chains
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) RT_S1(k);
+    } else if constexpr (MIX == RT_VALU_MIX_VALU_SALU) {
+        // full-rate vector and scalar instructions in turn, all independent: do the two pipes of a SIMD
+        // take instructions side by side (from different waves), or one after the other?
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                RT_P1("v_mul_f32_e32", k);
+                RT_S1(k & 7);
+            }
+    } else if constexpr (MIX == RT_VALU_MIX_SLOW_SALU) {
+        // the same with half-rate vector instructions (selects on a scalar mask)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(r[k]) : "v"(a), "s"(m0));
+                RT_S1(k & 7);
+            }
+    } else if constexpr (MIX == RT_VALU_MIX_FMA) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -178,6 +205,7 @@ __device__ __forceinline__ void probe_body(float (&r)[16], pf2 (&p)[8], float a,
     }
 }
 
+#undef RT_S1
 #undef RT_P1
 #undef RT_P2
 #undef RT_PK1
@@ -202,13 +230,16 @@ __global__ __launch_bounds__(256) void valu_probe_kernel(uint32_t ticks, unsigne
     const float a = 1.0000001f, b = 1.0e-7f;
     const pf2 pa = {1.0000001f, 0.9999999f}, pb = {1.0e-7f, -1.0e-7f};
     unsigned long long m0 = __ballot(threadIdx.x & 1), m1 = __ballot(threadIdx.x & 2);
+    uint32_t sg[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sg[k] = blockIdx.x + (uint32_t)k;
 
     __syncthreads();
     const unsigned long long t0 = __builtin_amdgcn_s_memtime(), w0 = __builtin_amdgcn_s_memrealtime();
     unsigned long long w1 = w0, bodies = 0;
     do {
 #pragma unroll 1
-        for (int i = 0; i < 8; ++i) probe_body<MIX>(r, p, a, b, pa, pb, m0, m1);
+        for (int i = 0; i < 8; ++i) probe_body<MIX>(r, p, a, b, pa, pb, m0, m1, sg);
         bodies += 8;
         w1 = __builtin_amdgcn_s_memrealtime();
     } while (w1 - w0 < ticks);
@@ -221,6 +252,8 @@ __global__ __launch_bounds__(256) void valu_probe_kernel(uint32_t ticks, unsigne
 #pragma unroll
     for (int k = 0; k < 8; ++k) s += p[k].x + p[k].y;
     s += (float)__popcll(m0 ^ m1);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += (float)sg[k];
     sink[blockIdx.x * blockDim.x + threadIdx.x] = s;
     if ((threadIdx.x & 63u) == 0u) {
         const uint32_t wave = blockIdx.x * (blockDim.x / 64u) + threadIdx.x / 64u;
@@ -288,6 +321,9 @@ extern "C" int rt_probe_valu_issue(int device, int mix, uint32_t waves_per_simd,
             RT_CASE(RT_VALU_MIX_DPP);
             RT_CASE(RT_VALU_MIX_BFI);
             RT_CASE(RT_VALU_MIX_AND_OR);
+            RT_CASE(RT_VALU_MIX_SALU);
+            RT_CASE(RT_VALU_MIX_VALU_SALU);
+            RT_CASE(RT_VALU_MIX_SLOW_SALU);
 #undef RT_CASE
         }
         if (e != hipSuccess || hipEventRecord(e1, 0) != hipSuccess || hipEventSynchronize(e1) != hipSuccess) rc = RT_ERR_HIP;
