@@ -211,7 +211,6 @@ enum : uint32_t { CT_NEW_PIXEL = 0, CT_NEW_PATH = 1, CT_START_SEGMENT = 2, CT_NE
 // instance records read with a wave-uniform index: the constant address space lets them come
 // through the scalar cache into scalar registers
 typedef const __attribute__((address_space(4))) DevInstance* ConstInstance;
-constexpr uint32_t kNoItem = 0xFFFFFFFFu;
 
 // A yes/no per lane held as a 64-bit mask in scalar registers: lanes_where() is what a vector
 // comparison writes anyway, lane_of() hands a mask back as a per-lane condition (for a select, a
@@ -219,6 +218,20 @@ constexpr uint32_t kNoItem = 0xFFFFFFFFu;
 typedef unsigned long long lmask;
 __device__ __forceinline__ lmask lanes_where(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 __device__ __forceinline__ bool lane_of(lmask m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
+// x + 1 / x - 1 in the lanes of a mask, x elsewhere: the mask goes in as the carry of one add / subtract
+// (a select and an add otherwise)
+__device__ __forceinline__ uint32_t add_lanes(uint32_t x, lmask m) {
+    uint32_t r;
+    lmask carry_out;
+    asm("v_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(r), "=s"(carry_out) : "v"(x), "s"(m));
+    return r;
+}
+__device__ __forceinline__ uint32_t sub_lanes(uint32_t x, lmask m) {
+    uint32_t r;
+    lmask carry_out;
+    asm("v_subb_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(r), "=s"(carry_out) : "v"(x), "s"(m));
+    return r;
+}
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -267,7 +280,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((COUNT |
     };
 
     // what names node record `a` / where a named item and a triangle's test record live
-    auto node_item = [&](uint32_t a) -> uint32_t { return BIG ? sc.node_unit + a : sc.node_off + a * 64u; };
+    // `cur` of a lane in ST_DESC / ST_POP names a child slot of a node record: the record's byte offset in the
+    // arena with the slot (0 / 1) in bit 0 -- records are 64 bytes apart, so the record is `cur & ~1` -- or, BIG,
+    // (node index << 1) | slot.  slot_of_node: slot 0 of node a; slot_item: the item of the slot's record.
+    auto slot_of_node = [&](uint32_t a) -> uint32_t { return BIG ? a << 1 : sc.node_off + a * 64u; };
+    auto slot_item = [&](uint32_t c) -> uint32_t { return BIG ? sc.node_unit + (c >> 1) : c & ~1u; };
     auto item_ptr = [&](uint32_t item) -> const f4* {
         return reinterpret_cast<const f4*>(BIG ? sc.arena + ((unsigned long long)item << 6) : sc.arena + item);
     };
@@ -300,19 +317,22 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((COUNT |
     lmask m_rcp_ok = 0ull;  // wave-uniform: the lanes whose ray is in the operand range of the cached-reciprocal division
     bool cull = false;
     f4 it0 = {0.0f, 0.0f, 0.0f, 0.0f}, it1 = it0, it2 = it0, it3 = it0;  // the pending item
-    uint32_t cur = 0;  // ST_DESC / ST_POP: (node index << 1) | child slot;  ST_LEAF: triangle index
+    uint32_t cur = 0;  // ST_DESC / ST_POP: a child slot of a node record (see slot_of_node);  ST_LEAF: triangle index
     uint32_t tri_last = 0, sp = 0;
 
     // Wave-uniform condition: lanes that have run out of pixels stay in the loop, inert, until
     // the whole wave is done, so that the cross-lane operations of the LEAF step always see all
     // 64 lanes.
     for (;;) {
-        uint32_t next_off = kNoItem;
+        lmask m_load = 0ull;  // wave-uniform: the lanes that have moved to a slot of another node record in this iteration
         const unsigned long long t_begin = COUNT ? __builtin_readcyclecounter() : 0ull;
         // wave-uniform choice of the one kind of step this iteration runs; a wave in which no lane waits
         // for any kind (every lane is out of pixels) is done
         const lmask m_ctl = lanes_where(phase == ST_CONTROL), m_leaf_wait = lanes_where(phase == ST_LEAF);
-        const lmask m_box_wait = lanes_where(phase == ST_DESC) | lanes_where(phase == ST_POP);
+        // (the BOX step takes these two masks over as they are: formed again there, the comparisons' results
+        // would cross the branch as per-lane values and be turned back into masks, four instructions for nothing)
+        const lmask m_desc_top = lanes_where(phase == ST_DESC), m_pop_top = lanes_where(phase == ST_POP);
+        const lmask m_box_wait = m_desc_top | m_pop_top;
         if ((m_ctl | m_leaf_wait | m_box_wait) == 0ull) break;
         const int w_ctl = __popcll(m_ctl) * q.w_ctl;
         const int w_box = __popcll(m_box_wait) * q.w_box;
@@ -444,8 +464,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((COUNT |
         } else {
 #include "traverse_steps.inc"
         }
-        if (next_off != kNoItem) {
-            const f4* p = item_ptr(next_off);
+        if (lane_of(m_load)) {
+            const f4* p = item_ptr(slot_item(cur));
             it0 = p[0];
             it1 = p[1];
             it2 = p[2];
@@ -528,7 +548,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((COUNT |
             site_wait[site] += __builtin_readcyclecounter() - t0;
         }
     };
-    auto node_item = [&](uint32_t a) -> uint32_t { return BIG ? sc.node_unit + a : sc.node_off + a * 64u; };
+    // `cur` of a lane in ST_DESC / ST_POP names a child slot of a node record: the record's byte offset in the
+    // arena with the slot (0 / 1) in bit 0 -- records are 64 bytes apart, so the record is `cur & ~1` -- or, BIG,
+    // (node index << 1) | slot.  slot_of_node: slot 0 of node a; slot_item: the item of the slot's record.
+    auto slot_of_node = [&](uint32_t a) -> uint32_t { return BIG ? a << 1 : sc.node_off + a * 64u; };
+    auto slot_item = [&](uint32_t c) -> uint32_t { return BIG ? sc.node_unit + (c >> 1) : c & ~1u; };
     auto item_ptr = [&](uint32_t item) -> const f4* {
         return reinterpret_cast<const f4*>(BIG ? sc.arena + ((unsigned long long)item << 6) : sc.arena + item);
     };
@@ -562,18 +586,19 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((COUNT |
     lmask m_rcp_ok = 0ull;  // wave-uniform: the lanes whose ray is in the operand range of the cached-reciprocal division
     bool cull = false;
     f4 it0 = {0.0f, 0.0f, 0.0f, 0.0f}, it1 = it0, it2 = it0, it3 = it0;  // the pending item
-    uint32_t cur = 0;  // ST_DESC / ST_POP: (node index << 1) | child slot;  ST_LEAF: triangle index
+    uint32_t cur = 0;  // ST_DESC / ST_POP: a child slot of a node record (see slot_of_node);  ST_LEAF: triangle index
     uint32_t tri_last = 0, sp = 0;
 
     while (n_live != 0u) {
-        uint32_t next_off = kNoItem;
+        lmask m_load = 0ull;  // wave-uniform: the lanes that have moved to a slot of another node record in this iteration
         const unsigned long long t_begin = COUNT ? __builtin_readcyclecounter() : 0ull;
         // wave-uniform choice of the one kind of step this iteration runs
         const uint32_t n_ctl = (uint32_t)__popcll(__ballot(phase == ST_CONTROL && ctl != CT_IDLE));
         const uint32_t n_idle = (uint32_t)__popcll(__ballot(phase == ST_CONTROL && ctl == CT_IDLE));
         const uint32_t n_claim = n_idle < n_ready ? n_idle : n_ready;
         const int w_ctl = (int)(n_ctl + n_claim) * q.w_ctl;
-        const int w_box = __popcll(__ballot(phase == ST_DESC || phase == ST_POP)) * q.w_box;
+        const lmask m_desc_top = lanes_where(phase == ST_DESC), m_pop_top = lanes_where(phase == ST_POP);
+        const int w_box = __popcll(m_desc_top | m_pop_top) * q.w_box;
         const int w_leaf = __popcll(__ballot(phase == ST_LEAF)) * q.w_leaf;
         const uint32_t n_shadeable = n_pending + n_new;
         int pick = 1, w_best = w_box;
@@ -812,8 +837,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((COUNT |
         } else {
 #include "traverse_steps.inc"
         }
-        if (next_off != kNoItem) {
-            const f4* p = item_ptr(next_off);
+        if (lane_of(m_load)) {
+            const f4* p = item_ptr(slot_item(cur));
             it0 = p[0];
             it1 = p[1];
             it2 = p[2];
