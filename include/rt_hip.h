@@ -82,7 +82,7 @@ enum {
      *     the same canvas; 0 = always in plain order. */
     RT_OPT_TILE_ORDER = 7,
     /* Weights of the wave's vote between control, box and triangle steps: three bytes,
-     * control | box << 8 | triangle << 16, each 1..255.  Default 3, 2, 6. */
+     * control | box << 8 | triangle << 16, each 1..255.  Default 4, 5, 15. */
     RT_OPT_VOTE_WEIGHTS = 8,
     /* Resident workgroups per CU: 0 (default) = as many as fit, else at most this many. */
     RT_OPT_BLOCKS_PER_CU = 9,

@@ -98,6 +98,13 @@ struct DevCam {
     float X[3], Y[3], Z[3], T[3];  // camera-to-world
     float edge_dist;               // tan(fov/2), evaluated once on the host
     float fw, fh, aspect;          // W, H, H/W as f32
+    // what every camera ray would compute anew with the same result (trace.rs:35-37): the ray origin
+    // transform_point3(0) = ((X*0 + Y*0) + Z*0) + T, formed on the host by those very operations, and the
+    // correctly rounded reciprocals of fw and fh with which px / fw and py / fh are formed as exact IEEE
+    // quotients in five instructions (div_by_rcp of fastdiv.hpp; fast_px: W and H are in its divisor range)
+    float pos[3];
+    float rcp_fw, rcp_fh;
+    uint32_t fast_px;
     uint32_t W, H;
     uint32_t depth;
     uint32_t frame;

@@ -33,6 +33,9 @@ void apply_material(DevInstance& inst, const rt_material& m);
 // The transform part of a DevInstance (inverse, forward, object id, copy of the object's root
 // record) from an rt_instance; the material fields are left alone.
 void set_instance_transform(DevInstance& di, const rt_instance& inst, const std::vector<DevObject>& objects);
+// After every instance's transform part is in place: which instances the cull above the instance list is
+// tried on (bound_ok is cleared for instances whose box fills the scene; pixels and counters do not change).
+void choose_cull_candidates(std::vector<DevInstance>& instances);
 void default_material(uint32_t instance_id, rt_material& m);
 
 }  // namespace rt

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "../../include/rt_hip.h"
+#include "fastdiv.hpp"
 #include "gpu_layout.hpp"
 #include "host_scene.hpp"
 #include "kernels.hpp"
@@ -123,6 +124,17 @@ DevCam make_cam(const rt_cam_data& cam, uint32_t frame_stride, uint32_t seed_mod
     d.fw = (float)cam.canvas_width;
     d.fh = (float)cam.canvas_height;
     d.aspect = (float)cam.canvas_height / (float)cam.canvas_width;  // trace.rs:31
+    // transform_point3(0), trace.rs:37: ((X*0 + Y*0) + Z*0) + T in binary32, one rounding per operation (this
+    // file is compiled without contraction and without value-changing optimisations, like the kernels)
+    for (int k = 0; k < 3; ++k) {
+        volatile float zx = d.X[k] * 0.0f, zy = d.Y[k] * 0.0f, zz = d.Z[k] * 0.0f;
+        volatile float s1 = zx + zy;
+        volatile float s2 = s1 + zz;
+        d.pos[k] = s2 + d.T[k];
+    }
+    d.rcp_fw = 1.0f / d.fw;
+    d.rcp_fh = 1.0f / d.fh;
+    d.fast_px = (div_den_ok(d.fw) && div_den_ok(d.fh)) ? 1u : 0u;
     d.W = cam.canvas_width;
     d.H = cam.canvas_height;
     d.depth = cam.depth;
@@ -526,6 +538,7 @@ int rt_update_instances(rt_ctx* c, const rt_instance* instances, size_t n) {
         if (instances[i].object_id >= c->h_objects.size())
             return fail(c, RT_ERR_INVALID, "instance " + std::to_string(i) + " references an object out of range");
     for (size_t i = 0; i < n; ++i) set_instance_transform(c->h_instances[i], instances[i], c->h_objects);
+    choose_cull_candidates(c->h_instances);
     RT_HIP(c, hipSetDevice(c->device));
     RT_HIP(c, hipStreamSynchronize(c->stream));  // frames in flight still read the old records
     RT_HIP(c, hipMemcpy(c->d_arena + c->inst_off, c->h_instances.data(), c->h_instances.size() * sizeof(DevInstance),

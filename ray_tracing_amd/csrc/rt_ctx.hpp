@@ -58,7 +58,7 @@ struct rt_ctx {
     uint32_t order_sig[5] = {0, 0, 0, 0, 0};
     bool tile_order_enabled = true;
     int n_cus = 0;
-    int vote_w[3] = {3, 2, 6};  // vote weights: control, box, triangle steps
+    int vote_w[3] = {4, 5, 15};  // vote weights: control, box, triangle steps
     uint32_t pool_slots = 0;     // RT_OPT_POOL_SLOTS
     int tile_deal = -1;          // -1: by launch length; 0 / 1: RT_OPT_TILE_DEAL
     int blocks_per_cu = 0;       // 0: as many as fit; RT_OPT_BLOCKS_PER_CU

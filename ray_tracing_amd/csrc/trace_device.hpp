@@ -159,14 +159,23 @@ struct Ray {
 
 // ---- camera: trace.rs:25-40 (tan hoisted to the host) ---------------------------
 RT_DEV Ray camera_ray(const DevCam& cam, float px, float py) {
-    float fx = (px / cam.fw) * 2.0f - 1.0f;
-    float fy = (py / cam.fh) * 2.0f - 1.0f;
+    // px = x + jitter is 0 or at least 1/65535 and at most W + 1: inside the numerator range of div_by_rcp
+    // whenever the divisor is (cam.fast_px)
+    float qx, qy;
+    if (cam.fast_px != 0u) {
+        qx = div_by_rcp(px, cam.fw, cam.rcp_fw);
+        qy = div_by_rcp(py, cam.fh, cam.rcp_fh);
+    } else {
+        qx = px / cam.fw;
+        qy = py / cam.fh;
+    }
+    float fx = qx * 2.0f - 1.0f;
+    float fy = qy * 2.0f - 1.0f;
     float fy_adj = fy * cam.aspect;
     V3 o = v3(fx * cam.edge_dist, fy_adj * cam.edge_dist, 1.0f);
     Ray r;
     r.dir = (ld3(cam.X) * o.x + ld3(cam.Y) * o.y) + ld3(cam.Z) * o.z;
-    // transform_point3(0): ((X*0 + Y*0) + Z*0) + T
-    r.pos = ((ld3(cam.X) * 0.0f + ld3(cam.Y) * 0.0f) + ld3(cam.Z) * 0.0f) + ld3(cam.T);
+    r.pos = ld3(cam.pos);  // transform_point3(0), the same for every ray: formed once on the host
     return r;
 }
 
