@@ -47,7 +47,7 @@ STRIP_H = 8
 # includes, and the code that makes the tree and the device records the kernel walks
 PROFILED_SOURCES = ("kernels.hip", "traverse_steps.inc", "instance_walk.inc", "trace_device.hpp", "fastdiv.hpp",
                     "trifilter.hpp", "fastexact.hpp", "wave_scan.hpp", "device_types.hpp", "kernels.hpp", "Makefile",
-                    "bvh_sah_gpu.hip", "bvh_pad.hpp", "gpu_layout.cpp", "host_scene.cpp")
+                    "bvh_sah_gpu.hip", "bvh_pad.hpp", "gpu_layout.cpp", "host_scene.cpp", "instance_cull.hpp", "rt_ctx.hpp")
 
 
 def profiled_source_hash():
