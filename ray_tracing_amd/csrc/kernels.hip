@@ -322,18 +322,18 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((COUNT |
 
     // Wave-uniform condition: lanes that have run out of pixels stay in the loop, inert, until
     // the whole wave is done, so that the cross-lane operations of the LEAF step always see all
-    // 64 lanes.
-    for (;;) {
+    // 64 lanes.  (A launch for no frames has nothing to do and would never see a lane run out.)
+    if (n_frames != 0u) for (;;) {
         lmask m_load = 0ull;  // wave-uniform: the lanes that have moved to a slot of another node record in this iteration
         const unsigned long long t_begin = COUNT ? __builtin_readcyclecounter() : 0ull;
-        // wave-uniform choice of the one kind of step this iteration runs; a wave in which no lane waits
-        // for any kind (every lane is out of pixels) is done
+        // wave-uniform choice of the one kind of step this iteration runs (a wave in which no lane waits for
+        // any kind is done: every lane is out of pixels, which only a CONTROL step can bring about, so that
+        // is where it is looked for)
         const lmask m_ctl = lanes_where(phase == ST_CONTROL), m_leaf_wait = lanes_where(phase == ST_LEAF);
         // (the BOX step takes these two masks over as they are: formed again there, the comparisons' results
         // would cross the branch as per-lane values and be turned back into masks, four instructions for nothing)
         const lmask m_desc_top = lanes_where(phase == ST_DESC), m_pop_top = lanes_where(phase == ST_POP);
         const lmask m_box_wait = m_desc_top | m_pop_top;
-        if ((m_ctl | m_leaf_wait | m_box_wait) == 0ull) break;
         const int w_ctl = __popcll(m_ctl) * q.w_ctl;
         const int w_box = __popcll(m_box_wait) * q.w_box;
         const int w_leaf = __popcll(m_leaf_wait) * q.w_leaf;
@@ -461,6 +461,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((COUNT |
                 }
                 if (__ballot(phase == ST_CONTROL && ctl == CT_NEXT_INSTANCE) == 0ull) break;
             }
+            if (lanes_where(phase != ST_DEAD) == 0ull) break;  // the wave is done
         } else {
 #include "traverse_steps.inc"
         }
