@@ -331,8 +331,9 @@ int rt_create_bvh_device(int device, const rt_vertex* vertices, size_t n_vertice
  * splits by the reference's own cost function (area(L) * |L| + area(R) * |R|, bvh.rs:109) and
  * its rule "split while a node holds more than leaf_max triangles" (bvh.rs:75-94), the cost
  * evaluated at 15 planes per axis between 16 bins of the node's centroid bounds, all nodes of a
- * level at once.  Same contract and node format as rt_create_bvh_device; the same input always
- * gives the same array.  `max_levels` bounds the number of node levels (0: 33, what the
+ * level at once while nodes are large; the subtree of a node of 2048 triangles or fewer is finished
+ * by one workgroup in LDS (same bins, same cost, same rules: the same subtree).  Same contract and
+ * node format as rt_create_bvh_device; the same input always gives the same array.  `max_levels` bounds the number of node levels (0: 33, what the
  * 32-entry traversal stack of the fast kernels takes; at most 65): a split that would leave a
  * side too big for the levels that remain is replaced by a cut in the middle of the range.
  * When leaf_max * 2^(max_levels - 1) < n_triangles no tree of that many levels has leaves that
@@ -341,6 +342,12 @@ int rt_create_bvh_device(int device, const rt_vertex* vertices, size_t n_vertice
 int rt_create_bvh_device_sah(int device, const rt_vertex* vertices, size_t n_vertices, rt_tri* triangles,
                              size_t n_triangles, uint32_t leaf_max, uint32_t max_levels, rt_bvh* nodes,
                              size_t* n_nodes);
+/* The same builder with every level taken through the level-wide passes (no subtree is handed to a
+ * workgroup): the same tree -- the same boxes, triangle ranges and triangle order at every node --
+ * with its nodes numbered level by level throughout.  Slower; kept as the check of the other. */
+int rt_create_bvh_device_sah_passes_only(int device, const rt_vertex* vertices, size_t n_vertices, rt_tri* triangles,
+                                         size_t n_triangles, uint32_t leaf_max, uint32_t max_levels, rt_bvh* nodes,
+                                         size_t* n_nodes);
 
 /* SceneBuilder (mod.rs:38-134) */
 rt_scene_builder* rt_scene_builder_new(void);

@@ -173,6 +173,7 @@ SIGNATURES = {
     "rt_create_bvh": (_i32, [_vp, _sz, _vp, _sz, _P(BvhParams), _vp, _P(_sz)]),
     "rt_create_bvh_device": (_i32, [_i32, _vp, _sz, _vp, _sz, C.c_uint32, _vp, _P(_sz)]),
     "rt_create_bvh_device_sah": (_i32, [_i32, _vp, _sz, _vp, _sz, C.c_uint32, C.c_uint32, _vp, _P(_sz)]),
+    "rt_create_bvh_device_sah_passes_only": (_i32, [_i32, _vp, _sz, _vp, _sz, C.c_uint32, C.c_uint32, _vp, _P(_sz)]),
     "rt_scene_builder_new": (_vp, []),
     "rt_scene_builder_free": (None, [_vp]),
     "rt_scene_builder_add_obj": (_i32, [_vp, C.c_char_p, _sz, _vp, _sz, _P(BvhParams)]),

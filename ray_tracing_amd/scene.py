@@ -92,7 +92,8 @@ def create_bvh_gpu(positions, triangles, leaf_max=4, device=0, method="linear", 
     """A BVH built on the GPU: returns the triangles in the order the tree wants them and the
     nodes in the reference's 48-byte format (node 0 is the root).  method "linear": Morton-sorted
     linear BVH (rt_create_bvh_device); "sah": binned surface-area splits by the reference's cost
-    function (rt_create_bvh_device_sah)."""
+    function (rt_create_bvh_device_sah); "sah_passes": the same tree built by level-wide passes only
+    (rt_create_bvh_device_sah_passes_only)."""
     lib = L.load()
     v = np.zeros(len(positions), VERTEX_DT)
     v["pos"] = np.ascontiguousarray(positions, np.float32)
@@ -101,10 +102,11 @@ def create_bvh_gpu(positions, triangles, leaf_max=4, device=0, method="linear", 
     if method == "linear":
         def call(nodes_ptr):
             return lib.rt_create_bvh_device(device, _ptr(v), len(v), _ptr(t), len(t), leaf_max, nodes_ptr, C.byref(n))
-    elif method == "sah":
+    elif method in ("sah", "sah_passes"):
+        build = lib.rt_create_bvh_device_sah if method == "sah" else lib.rt_create_bvh_device_sah_passes_only
+
         def call(nodes_ptr):
-            return lib.rt_create_bvh_device_sah(device, _ptr(v), len(v), _ptr(t), len(t), leaf_max, max_levels,
-                                                nodes_ptr, C.byref(n))
+            return build(device, _ptr(v), len(v), _ptr(t), len(t), leaf_max, max_levels, nodes_ptr, C.byref(n))
     else:
         raise ValueError(method)
     rc = call(None)

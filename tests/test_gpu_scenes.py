@@ -486,6 +486,46 @@ def test_gpu_built_sah_bvh_of_a_million_triangles_is_exact_everywhere():
     assert (key(tris) == key(faces)).all(), "the triangles are not a permutation of the input"
 
 
+def assert_same_tree(nodes_a, nodes_b):
+    """Two node arrays describe one and the same tree -- the same box, mode and triangle range at every
+    node, the same children in the same order -- whatever numbers the nodes carry.  Level by level from
+    the two roots."""
+    ia, ib = np.array([0], np.int64), np.array([0], np.int64)
+    seen = 0
+    while len(ia):
+        a, b = nodes_a[ia], nodes_b[ib]
+        assert (a["mode"] == b["mode"]).all()
+        assert a["min"].tobytes() == b["min"].tobytes() and a["max"].tobytes() == b["max"].tobytes()
+        leaf = a["mode"] == 1
+        assert (a["c1"][leaf] == b["c1"][leaf]).all() and (a["c2"][leaf] == b["c2"][leaf]).all()
+        seen += len(ia)
+        inner = ~leaf
+        ia = np.concatenate([a["c1"][inner], a["c2"][inner]]).astype(np.int64)
+        ib = np.concatenate([b["c1"][inner], b["c2"][inner]]).astype(np.int64)
+    assert seen == len(nodes_a) == len(nodes_b)
+
+
+@pytest.mark.parametrize("grid,leaf_max,max_levels", [(40, 4, 0), (40, 1, 0), (40, 7, 12), (200, 4, 0), (200, 16, 0),
+                                                     (700, 4, 0)])
+def test_subtrees_finished_by_one_workgroup_are_the_ones_the_passes_make(grid, leaf_max, max_levels):
+    """rt_create_bvh_device_sah hands the subtree of a node of 2048 triangles or fewer to one workgroup;
+    rt_create_bvh_device_sah_passes_only takes every level through the level-wide passes.  Same bins,
+    same cost, same rules: the same tree and the same triangle order, numbered differently."""
+    verts, faces = S.terrain(n=grid)
+    faces = np.asarray(faces, np.uint32)
+    tris, nodes = S.create_bvh_gpu(verts, faces, leaf_max=leaf_max, method="sah", max_levels=max_levels)
+    tris_p, nodes_p = S.create_bvh_gpu(verts, faces, leaf_max=leaf_max, method="sah_passes", max_levels=max_levels)
+    assert tris.tobytes() == tris_p.tobytes()
+    assert_same_tree(nodes, nodes_p)
+    # coincident centroids (cuts by position) inside a subtree and above it
+    pos = np.asarray(verts, F)
+    same = np.tile(np.array([[0, 1, 2]], np.uint32), (5000, 1))
+    t1, n1 = S.create_bvh_gpu(pos[:3], same, leaf_max=leaf_max, method="sah")
+    t2, n2 = S.create_bvh_gpu(pos[:3], same, leaf_max=leaf_max, method="sah_passes")
+    assert t1.tobytes() == t2.tobytes()
+    assert_same_tree(n1, n2)
+
+
 def parse_obj(name):
     data = S._resource(name).encode()
     lib = L.load()
