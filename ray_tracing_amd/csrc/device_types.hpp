@@ -44,7 +44,12 @@ struct alignas(64) DevTri {
     float p0[3]; float nx;
     float p1[3]; float ny;
     float p2[3]; float nz;
-    float d;     float pad[3];
+    float d;
+    // The shading normal trace_ray forms at every hit (trace.rs:140-157: the triangle's vertices moved to
+    // world space by the instance's transform, normalize(cross(w0 - w1, w0 - w2))), formed once per
+    // triangle by the same operations (world_normals_kernel) when one and only one instance shows the
+    // triangle's object (DevInstance::normals_ready); unspecified otherwise.
+    float wn[3];
 };
 
 // What the persistent kernel's triangle step reads: the same plane, the first
@@ -79,7 +84,7 @@ struct alignas(64) DevInstance {
     uint32_t object_id;
     uint32_t mat_kind;
     float ior;
-    uint32_t pad1;
+    uint32_t normals_ready;  // 1: DevTri::wn of this instance's triangles holds their world-space shading normal
     float color[3];
     float specular;
     float specular_roughness;

@@ -107,6 +107,18 @@ void set_instance_transform(DevInstance& di, const rt_instance& inst, const std:
 // near that box.  Such instances keep their box but are marked "not tried" (bound_ok = 0).  An instance
 // counts as filling the scene when its box spans at least 0.6 of the extent of all the boxes together along
 // every axis.  Purely a matter of speed: tried or not, the pixels and counters are the same.
+void choose_normal_owners(std::vector<DevInstance>& instances, const std::vector<uint8_t>& object_shares,
+                          std::vector<uint32_t>& object_instance) {
+    std::vector<uint32_t> shown(object_shares.size(), 0);
+    for (const DevInstance& di : instances) shown[di.object_id] += 1;
+    object_instance.assign(object_shares.size(), kNoOwner);
+    for (size_t i = 0; i < instances.size(); ++i) {
+        DevInstance& di = instances[i];
+        di.normals_ready = (shown[di.object_id] == 1 && !object_shares[di.object_id]) ? 1u : 0u;
+        if (di.normals_ready) object_instance[di.object_id] = (uint32_t)i;
+    }
+}
+
 void choose_cull_candidates(std::vector<DevInstance>& instances) {
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (const DevInstance& di : instances) {
@@ -170,7 +182,7 @@ bool build_gpu_scene(const rt_scene_info& info, const rt_vertex* vertices, size_
             o.ny = normal.y;
             o.nz = normal.z;
             o.d = d;
-            o.pad[0] = o.pad[1] = o.pad[2] = 0.0f;
+            o.wn[0] = o.wn[1] = o.wn[2] = 0.0f;  // world_normals_kernel fills it in where it applies
             const float nf[3] = {normal.x, normal.y, normal.z};
             tri_filter_build(o.p0, o.p1, o.p2, nf, d, out.tri_tests[i]);
         }
@@ -227,6 +239,35 @@ bool build_gpu_scene(const rt_scene_info& info, const rt_vertex* vertices, size_
             return false;
         }
         if (depth > out.max_depth) out.max_depth = depth;
+    }
+
+    // which object shows which triangle (every link has been checked above)
+    out.tri_owner.assign(n_triangles, kNoOwner);
+    out.object_shares.assign(n_objects, 0);
+    {
+        std::vector<uint32_t> stack;
+        for (size_t obj = 0; obj < n_objects; ++obj) {
+            stack.assign(1, objects[obj].bvh_root);
+            while (!stack.empty()) {
+                const rt_bvh& nd = bvh[stack.back()];
+                stack.pop_back();
+                if (nd.mode == RT_MODE_CHILDREN) {
+                    stack.push_back(nd.child_1_or_first_tri);
+                    stack.push_back(nd.child_2_or_last_tri);
+                    continue;
+                }
+                if (nd.child_1_or_first_tri == nd.child_2_or_last_tri + 1u) continue;  // an empty leaf
+                for (uint32_t t = nd.child_1_or_first_tri; t <= nd.child_2_or_last_tri; ++t) {
+                    uint32_t& owner = out.tri_owner[t];
+                    if (owner == kNoOwner) {
+                        owner = (uint32_t)obj;
+                    } else if (owner != obj) {
+                        out.object_shares[owner] = 1;
+                        out.object_shares[obj] = 1;
+                    }
+                }
+            }
+        }
     }
 
     out.instances.resize(n_instances);

@@ -18,10 +18,15 @@ struct GpuScene {
     std::vector<DevTriTest> tri_tests;  // one per triangle
     std::vector<DevObject> objects;
     std::vector<DevInstance> instances;
+    // which object's tree holds each triangle (kNoOwner: none), and the objects that share a triangle with
+    // another object: what decides whether a triangle's world-space normal can be formed once (DevTri::wn)
+    std::vector<uint32_t> tri_owner;
+    std::vector<uint8_t> object_shares;
     uint32_t max_depth = 0;  // longest root-to-leaf path in nodes, over all objects
     bool fast_div = true;    // all box coordinates are in the range fastdiv.hpp asks for
 };
 
+constexpr uint32_t kNoOwner = 0xFFFFFFFFu;
 constexpr uint32_t kMaxBvhDepth = 65;  // deepest tree any kernel variant has stack for
 
 // Returns false and fills `err` when the buffers are inconsistent.
@@ -37,5 +42,10 @@ void set_instance_transform(DevInstance& di, const rt_instance& inst, const std:
 // tried on (bound_ok is cleared for instances whose box fills the scene; pixels and counters do not change).
 void choose_cull_candidates(std::vector<DevInstance>& instances);
 void default_material(uint32_t instance_id, rt_material& m);
+// After the instances' object ids are in place: normals_ready of every instance (the one instance of an
+// object that shares no triangle with another object), and per object the index of that instance
+// (kNoOwner: none) for world_normals_kernel.
+void choose_normal_owners(std::vector<DevInstance>& instances, const std::vector<uint8_t>& object_shares,
+                          std::vector<uint32_t>& object_instance);
 
 }  // namespace rt

@@ -893,6 +893,34 @@ __global__ __launch_bounds__(kBlock) void present_bytes_kernel(const float4* pre
     rgba8[i] = byte_of(p.x) | (byte_of(p.y) << 8) | (byte_of(p.z) << 16) | (byte_of(p.w) << 24);
 }
 
+// DevTri::wn of every triangle whose object is shown by exactly one instance: the world-space shading
+// normal, by the very function shade() would call at every hit of that triangle.  Run after a scene upload
+// and after the instances changed.  owner[i]: the object whose tree holds triangle i; object_instance[o]:
+// the one instance of object o, or 0xFFFFFFFF.
+__global__ __launch_bounds__(kBlock) void world_normals_kernel(DevTri* tris, uint32_t n, const uint32_t* owner,
+                                                               const uint32_t* object_instance,
+                                                               const DevInstance* instances) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t o = owner[i];
+    if (o == 0xFFFFFFFFu) return;
+    const uint32_t k = object_instance[o];
+    if (k == 0xFFFFFFFFu) return;
+    const float4* tp = reinterpret_cast<const float4*>(&tris[i]);
+    const V3 nrm = world_normal(instances[k].fwd, tp[0], tp[1], tp[2]);
+    tris[i].wn[0] = nrm.x;
+    tris[i].wn[1] = nrm.y;
+    tris[i].wn[2] = nrm.z;
+}
+
+hipError_t launch_world_normals(DevTri* tris, uint32_t n_tris, const uint32_t* owner, const uint32_t* object_instance,
+                                const DevInstance* instances, hipStream_t stream) {
+    if (n_tris == 0) return hipSuccess;
+    hipLaunchKernelGGL(world_normals_kernel, dim3((n_tris + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, tris, n_tris,
+                       owner, object_instance, instances);
+    return hipGetLastError();
+}
+
 hipError_t launch_present_bytes(const float* present, uint32_t n_pixels, uint32_t* rgba8, hipStream_t stream) {
     if (n_pixels == 0) return hipSuccess;
     hipLaunchKernelGGL(present_bytes_kernel, dim3((n_pixels + kBlock - 1) / kBlock), dim3(kBlock), 0, stream,

@@ -55,6 +55,12 @@ struct AccumulatorList {
 };
 hipError_t launch_sum_accumulators(float* out, const AccumulatorList& list, uint32_t n_pixels, hipStream_t stream);
 
+// DevTri::wn (the world-space shading normal) of every triangle whose object exactly one instance shows:
+// `owner` names each triangle's object, `object_instance` that object's one instance (0xFFFFFFFF: none or
+// several).  To run after the scene or the instances changed, before the next render on `stream`.
+hipError_t launch_world_normals(DevTri* tris, uint32_t n_tris, const uint32_t* owner, const uint32_t* object_instance,
+                                const DevInstance* instances, hipStream_t stream);
+
 // Binding 8 (RGBA32F) -> 8-bit RGBA, one word per pixel, R in the low byte.
 hipError_t launch_present_bytes(const float* present, uint32_t n_pixels, uint32_t* rgba8, hipStream_t stream);
 

@@ -45,7 +45,23 @@ void free_scene(rt_ctx* c) {
     free_dev(c->d_arena);
     free_dev(c->d_tris);
     free_dev(c->d_objects);
+    free_dev(c->d_tri_owner);
+    free_dev(c->d_object_instance);
     c->have_scene = false;
+}
+
+// The instance records (c->h_instances) to the device, and with them what follows from which instance shows
+// which object: normals_ready, and the world-space normals of the triangles it holds for (DevTri::wn).  The
+// caller has made sure that no frame in flight still reads the old records.
+int upload_instances(rt_ctx* c) {
+    std::vector<uint32_t> object_instance;
+    choose_normal_owners(c->h_instances, c->h_object_shares, object_instance);
+    RT_HIP(c, hipMemcpy(c->d_arena + c->inst_off, c->h_instances.data(), c->h_instances.size() * sizeof(DevInstance),
+                        hipMemcpyHostToDevice));
+    RT_HIP(c, hipMemcpy(c->d_object_instance, object_instance.data(), object_instance.size() * 4, hipMemcpyHostToDevice));
+    RT_HIP(c, launch_world_normals(c->d_tris, (uint32_t)c->n_tris, c->d_tri_owner, c->d_object_instance,
+                                   reinterpret_cast<const DevInstance*>(c->d_arena + c->inst_off), c->stream));
+    return RT_OK;
 }
 
 void free_frame(rt_ctx* c) {
@@ -515,10 +531,18 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_info* info, const rt_vertex* verti
         RT_HIP(c, hipMemcpy(c->d_arena + c->tri_test_off, g.tri_tests.data(), g.tri_tests.size() * sizeof(DevTriTest),
                             hipMemcpyHostToDevice));
     RT_HIP(c, hipMemcpy(c->d_objects, g.objects.data(), g.objects.size() * sizeof(DevObject), hipMemcpyHostToDevice));
-    RT_HIP(c, hipMemcpy(c->d_arena + c->inst_off, g.instances.data(), g.instances.size() * sizeof(DevInstance),
-                        hipMemcpyHostToDevice));
+    RT_HIP(c, hipMalloc(&c->d_tri_owner, n_tris * 4));
+    RT_HIP(c, hipMalloc(&c->d_object_instance, g.objects.size() * 4));
+    if (!g.tri_owner.empty())
+        RT_HIP(c, hipMemcpy(c->d_tri_owner, g.tri_owner.data(), g.tri_owner.size() * 4, hipMemcpyHostToDevice));
+    c->n_tris = g.tris.size();
     c->h_instances = g.instances;
     c->h_objects = g.objects;
+    c->h_object_shares = g.object_shares;
+    {
+        const int rc = upload_instances(c);
+        if (rc != RT_OK) return rc;
+    }
     c->n_instances = (uint32_t)g.instances.size();
     c->max_depth = g.max_depth;
     c->fast_div = g.fast_div;
@@ -541,9 +565,7 @@ int rt_update_instances(rt_ctx* c, const rt_instance* instances, size_t n) {
     choose_cull_candidates(c->h_instances);
     RT_HIP(c, hipSetDevice(c->device));
     RT_HIP(c, hipStreamSynchronize(c->stream));  // frames in flight still read the old records
-    RT_HIP(c, hipMemcpy(c->d_arena + c->inst_off, c->h_instances.data(), c->h_instances.size() * sizeof(DevInstance),
-                        hipMemcpyHostToDevice));
-    return RT_OK;
+    return upload_instances(c);
 }
 
 void rt_default_material(uint32_t instance_id, rt_material* out) {

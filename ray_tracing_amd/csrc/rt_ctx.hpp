@@ -24,6 +24,12 @@ struct rt_ctx {
     rt::DevObject* d_objects = nullptr;
     std::vector<rt::DevInstance> h_instances;
     std::vector<rt::DevObject> h_objects;
+    // world-space shading normals (DevTri::wn): each triangle's object, the objects that share triangles,
+    // and per object its one instance
+    uint32_t* d_tri_owner = nullptr;
+    uint32_t* d_object_instance = nullptr;
+    std::vector<uint8_t> h_object_shares;
+    size_t n_tris = 0;
     uint32_t n_instances = 0;
     uint32_t max_depth = 0;
     bool fast_div = false;

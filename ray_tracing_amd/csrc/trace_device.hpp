@@ -529,6 +529,15 @@ RT_DEV V3 sky_color(V3 ray_dir) {
     return v3(1.0f, 1.0f, 1.0f) * (1.0f - factor) + v3(0.5f, 0.7f, 1.0f) * factor;
 }
 
+// The shading normal of a hit, trace.rs:140-157: the triangle's vertices moved to world space by the
+// instance's transform, then normalize(cross(w0 - w1, w0 - w2)); never flipped toward the viewer.
+RT_DEV V3 world_normal(const float* fwd, float4 ta, float4 tb, float4 tc) {
+    V3 w0 = xf_point(fwd, v3(ta.x, ta.y, ta.z));
+    V3 w1 = xf_point(fwd, v3(tb.x, tb.y, tb.z));
+    V3 w2 = xf_point(fwd, v3(tc.x, tc.y, tc.z));
+    return normalize(cross(w0 - w1, w0 - w2));
+}
+
 // ---- the part of trace_ray after the instance loop: trace.rs:97-172 ------------------
 RT_DEV int shade(const DevScene& sc, const DevCam& cam, const HitRecord& record, Ray& self, uint32_t& seed,
                  V3& color) {
@@ -556,11 +565,14 @@ RT_DEV int shade(const DevScene& sc, const DevCam& cam, const HitRecord& record,
     }
     const DevInstance& inst = sc.instances[record.instance_id];
     const float4* tp = reinterpret_cast<const float4*>(&sc.tris[record.triangle_id]);
-    float4 ta = tp[0], tb = tp[1], tc = tp[2];
-    V3 w0 = xf_point(inst.fwd, v3(ta.x, ta.y, ta.z));
-    V3 w1 = xf_point(inst.fwd, v3(tb.x, tb.y, tb.z));
-    V3 w2 = xf_point(inst.fwd, v3(tc.x, tc.y, tc.z));
-    V3 normal = normalize(cross(w0 - w1, w0 - w2));
+    V3 normal;
+    if (inst.normals_ready != 0u) {
+        // formed once per triangle by world_normal() below, for the one instance that shows this object
+        const float4 td = tp[3];
+        normal = v3(td.y, td.z, td.w);
+    } else {
+        normal = world_normal(inst.fwd, tp[0], tp[1], tp[2]);
+    }
     if (inst.mat_kind == 0u) return generic_bxdf(inst, color, self, normal, record.t, seed);
     if (inst.mat_kind == 1u) return normal_bxdf(color, self, normal, record.t, seed);
     if (inst.mat_kind == 3u) return refractive_bxdf(inst, self, normal, record.t, seed);

@@ -804,6 +804,18 @@ def test_moving_instances_between_frames_equals_uploading_the_moved_scene():
         tri, inst, tb = app.read_hits()
         assert_bits_equal(tri, ref.hit_triangle, "triangle_id")
         assert_bits_equal(inst, ref.hit_instance, "instance_id")
+        # two instances showing one object (its triangles' world-space normals can no longer be formed once
+        # per triangle), then every object shown once again
+        shared = moved.copy()
+        shared["object_id"][2] = shared["object_id"][1]
+        shared_scene = S.Scene(scene.info, scene.vertices, scene.triangles, scene.objects, shared, scene.bvh)
+        for instances, its_scene in ((shared, shared_scene), (moved, moved_scene)):
+            want = O.OracleRenderer(its_scene, cam, trig=O.TRIG_DET).render(2)
+            app.update_instances(instances)
+            app.cam_data = copy_cam(cam)
+            app.clear_acc()
+            app.render_frames(2)
+            assert_bits_equal(app.read_acc().reshape(-1, 4), want.acc.reshape(-1, 4), "accumulator after the second move")
         with pytest.raises(RtError):
             app.update_instances(moved[:2])
         bad = moved.copy()
