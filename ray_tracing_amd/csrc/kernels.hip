@@ -317,7 +317,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((COUNT |
     lmask m_rcp_ok = 0ull;  // wave-uniform: the lanes whose ray is in the operand range of the cached-reciprocal division
     bool cull = false;
     f4 it0 = {0.0f, 0.0f, 0.0f, 0.0f}, it1 = it0, it2 = it0, it3 = it0;  // the pending item
-    uint32_t cur = 0;  // ST_DESC / ST_POP: a child slot of a node record (see slot_of_node);  ST_LEAF: triangle index
+    uint32_t cur = 0;       // ST_DESC / ST_POP: a child slot of a node record (see slot_of_node)
+    uint32_t leaf_cur = 0;  // ST_LEAF: the next triangle of the leaf (a register of its own, so that a BOX step need
+                            // not spare the lanes that stand at a leaf when it writes `cur`)
     uint32_t tri_last = 0, sp = 0;
 
     // Wave-uniform condition: lanes that have run out of pixels stay in the loop, inert, until
@@ -587,7 +589,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((COUNT |
     lmask m_rcp_ok = 0ull;  // wave-uniform: the lanes whose ray is in the operand range of the cached-reciprocal division
     bool cull = false;
     f4 it0 = {0.0f, 0.0f, 0.0f, 0.0f}, it1 = it0, it2 = it0, it3 = it0;  // the pending item
-    uint32_t cur = 0;  // ST_DESC / ST_POP: a child slot of a node record (see slot_of_node);  ST_LEAF: triangle index
+    uint32_t cur = 0;       // ST_DESC / ST_POP: a child slot of a node record (see slot_of_node)
+    uint32_t leaf_cur = 0;  // ST_LEAF: the next triangle of the leaf (a register of its own, so that a BOX step need
+                            // not spare the lanes that stand at a leaf when it writes `cur`)
     uint32_t tri_last = 0, sp = 0;
 
     while (n_live != 0u) {
