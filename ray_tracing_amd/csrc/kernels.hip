@@ -464,9 +464,17 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((COUNT |
                 if (__ballot(phase == ST_CONTROL && ctl == CT_NEXT_INSTANCE) == 0ull) break;
             }
             if (lanes_where(phase != ST_DEAD) == 0ull) break;  // the wave is done
-        } else {
+        } else if (pick == 2) {
+            // (each kind of step in a branch of its own, with its own copy of the pop that follows it)
+#define RT_STEP_ONLY_LEAF
 #include "traverse_steps.inc"
+#undef RT_STEP_ONLY_LEAF
+        } else {
+#define RT_STEP_ONLY_BOX
+#include "traverse_steps.inc"
+#undef RT_STEP_ONLY_BOX
         }
+        // the records of the lanes that moved on are fetched for their next step
         if (lane_of(m_load)) {
             const f4* p = item_ptr(slot_item(cur));
             it0 = p[0];
