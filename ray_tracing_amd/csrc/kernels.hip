@@ -325,33 +325,76 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((COUNT |
     // Wave-uniform condition: lanes that have run out of pixels stay in the loop, inert, until
     // the whole wave is done, so that the cross-lane operations of the LEAF step always see all
     // 64 lanes.  (A launch for no frames has nothing to do and would never see a lane run out.)
+    // Two loops, one in the other.  The inner one runs BOX and LEAF steps for as long as the vote asks for one
+    // of them; when it asks for a CONTROL step the inner loop ends, the outer loop's body runs that step and
+    // goes back in.  (One loop with the three kinds as branches of its body gives the same steps in the same
+    // order; but then the way out -- the wave is done, found in the CONTROL step -- leaves the loop from
+    // inside a branch, and the compiler pays for that with flags tested and registers copied on every
+    // iteration of every kind: 2 % of the launch.)
     if (n_frames != 0u) for (;;) {
         lmask m_load = 0ull;  // wave-uniform: the lanes that have moved to a slot of another node record in this iteration
-        const unsigned long long t_begin = COUNT ? __builtin_readcyclecounter() : 0ull;
-        // wave-uniform choice of the one kind of step this iteration runs (a wave in which no lane waits for
-        // any kind is done: every lane is out of pixels, which only a CONTROL step can bring about, so that
-        // is where it is looked for)
-        const lmask m_ctl = lanes_where(phase == ST_CONTROL), m_leaf_wait = lanes_where(phase == ST_LEAF);
-        // (the BOX step takes these two masks over as they are: formed again there, the comparisons' results
-        // would cross the branch as per-lane values and be turned back into masks, four instructions for nothing)
-        const lmask m_desc_top = lanes_where(phase == ST_DESC), m_pop_top = lanes_where(phase == ST_POP);
-        const lmask m_box_wait = m_desc_top | m_pop_top;
-        const int w_ctl = __popcll(m_ctl) * q.w_ctl;
-        const int w_box = __popcll(m_box_wait) * q.w_box;
-        const int w_leaf = __popcll(m_leaf_wait) * q.w_leaf;
-        int pick = 1, w_best = w_box;
-        if (w_leaf > w_best) pick = 2, w_best = w_leaf;
-        if (w_ctl > w_best) pick = 0;
-        if (COUNT) {
-            // profile only: how long the prefetched item still takes to arrive
-            const unsigned long long t0 = __builtin_readcyclecounter();
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            sched_wait[pick] += __builtin_readcyclecounter() - t0;
-            sched_iters[pick] += 1;
-            sched_lanes[pick] += (unsigned)(pick == 0 ? w_ctl / q.w_ctl : pick == 1 ? w_box / q.w_box : w_leaf / q.w_leaf);
-        }
+        unsigned long long t_begin = 0ull;
+        for (;;) {
+            m_load = 0ull;
+            t_begin = COUNT ? __builtin_readcyclecounter() : 0ull;
+            // wave-uniform choice of the one kind of step this iteration runs (a wave in which no lane waits for
+            // any kind is done: every lane is out of pixels, which only a CONTROL step can bring about, so that
+            // is where it is looked for)
+            const lmask m_ctl = lanes_where(phase == ST_CONTROL), m_leaf_wait = lanes_where(phase == ST_LEAF);
+            // (the BOX step takes these two masks over as they are: formed again there, the comparisons' results
+            // would cross the branch as per-lane values and be turned back into masks, four instructions for nothing)
+            const lmask m_desc_top = lanes_where(phase == ST_DESC), m_pop_top = lanes_where(phase == ST_POP);
+            const lmask m_box_wait = m_desc_top | m_pop_top;
+            const int w_ctl = __popcll(m_ctl) * q.w_ctl;
+            const int w_box = __popcll(m_box_wait) * q.w_box;
+            const int w_leaf = __popcll(m_leaf_wait) * q.w_leaf;
+            int pick = 1, w_best = w_box;
+            if (w_leaf > w_best) pick = 2, w_best = w_leaf;
+            if (w_ctl > w_best) pick = 0;
+            if (COUNT) {
+                // profile only: how long the prefetched item still takes to arrive
+                const unsigned long long t0 = __builtin_readcyclecounter();
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                sched_wait[pick] += __builtin_readcyclecounter() - t0;
+                sched_iters[pick] += 1;
+                sched_lanes[pick] += (unsigned)(pick == 0 ? w_ctl / q.w_ctl : pick == 1 ? w_box / q.w_box : w_leaf / q.w_leaf);
+            }
 
-        if (pick == 0) {
+            if (pick == 0) break;
+            // (each kind of step with its own copy of the pop that follows it; the BOX step, four iterations
+            // in five, also with its own copy of the fetch and its own way back to the top, so that none of
+            // its results crosses a point where the two kinds meet: 0.7 % of the launch)
+            if (pick == 1) {
+#define RT_STEP_ONLY_BOX
+#include "traverse_steps.inc"
+#undef RT_STEP_ONLY_BOX
+                // the records of the lanes that moved on are fetched for their next step
+                if (lane_of(m_load)) {
+                    const f4* p = item_ptr(slot_item(cur));
+                    it0 = p[0];
+                    it1 = p[1];
+                    it2 = p[2];
+                    it3 = p[3];
+                }
+                if (COUNT) sched_cycles[pick] += __builtin_readcyclecounter() - t_begin;
+                continue;
+            }
+            {
+#define RT_STEP_ONLY_LEAF
+#include "traverse_steps.inc"
+#undef RT_STEP_ONLY_LEAF
+            }
+            if (lane_of(m_load)) {
+                const f4* p = item_ptr(slot_item(cur));
+                it0 = p[0];
+                it1 = p[1];
+                it2 = p[2];
+                it3 = p[3];
+            }
+            if (COUNT) sched_cycles[pick] += __builtin_readcyclecounter() - t_begin;
+        }
+        const int pick = 0;  // the CONTROL step
+        {
             // one queue per XCD group; every lane that needs a pixel takes part in one fetch
             const bool want = phase == ST_CONTROL && ctl == CT_NEW_PIXEL;
             const unsigned long long wm = __ballot(want);
@@ -463,17 +506,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((COUNT |
                 }
                 if (__ballot(phase == ST_CONTROL && ctl == CT_NEXT_INSTANCE) == 0ull) break;
             }
-            if (lanes_where(phase != ST_DEAD) == 0ull) break;  // the wave is done
-        } else if (pick == 2) {
-            // (each kind of step in a branch of its own, with its own copy of the pop that follows it)
-#define RT_STEP_ONLY_LEAF
-#include "traverse_steps.inc"
-#undef RT_STEP_ONLY_LEAF
-        } else {
-#define RT_STEP_ONLY_BOX
-#include "traverse_steps.inc"
-#undef RT_STEP_ONLY_BOX
         }
+        if (lanes_where(phase != ST_DEAD) == 0ull) break;  // the wave is done
         // the records of the lanes that moved on are fetched for their next step
         if (lane_of(m_load)) {
             const f4* p = item_ptr(slot_item(cur));
