@@ -293,7 +293,18 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((COUNT |
                                                : sc.arena + (sc.tri_test_off + tri * 64u));
     };
     const ConstInstance inst_base = (ConstInstance)(uintptr_t)sc.instances;
-    uint32_t phase = n_frames > 0 ? ST_CONTROL : ST_DEAD;
+    // What kind of step each lane waits for, as four wave-uniform lane masks (a lane in none of them is out of
+    // pixels): the vote counts their bits, a step hands its own yes/no masks on as the new phases, and no lane
+    // carries a phase number that would have to be compared four times per iteration and selected four times
+    // per BOX step.
+    lmask pm_ctl = n_frames > 0 ? ~0ull : 0ull, pm_desc = 0ull, pm_pop = 0ull, pm_leaf = 0ull;
+#define RT_PHASE_IN_CONTROL lane_of(pm_ctl)
+#define RT_PHASE_AT_LEAF lane_of(pm_leaf)
+#define RT_PHASE_AFTER_BOX(m_internal_, m_leaf_) (pm_desc = (m_internal_), pm_pop = 0ull, pm_leaf |= (m_leaf_))
+#define RT_PHASE_AFTER_LEAF(m_finished_) (pm_leaf &= ~(m_finished_))
+#define RT_PHASE_AFTER_POP(m_pop_, m_inst_end_) (pm_pop |= (m_pop_), pm_ctl |= (m_inst_end_))
+#define RT_PHASE_ENTER(enter_node_, enter_leaf_)                                                          \
+    (pm_desc |= lanes_where(enter_node_), pm_leaf |= lanes_where(enter_leaf_), pm_ctl &= ~lanes_where((enter_node_) || (enter_leaf_)))
     uint32_t ctl = CT_NEW_PIXEL;
     uint32_t queues_tried = 0;  // wave-uniform: how many queues this wave has found empty
     // pixel state
@@ -340,10 +351,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((COUNT |
             // wave-uniform choice of the one kind of step this iteration runs (a wave in which no lane waits for
             // any kind is done: every lane is out of pixels, which only a CONTROL step can bring about, so that
             // is where it is looked for)
-            const lmask m_ctl = lanes_where(phase == ST_CONTROL), m_leaf_wait = lanes_where(phase == ST_LEAF);
-            // (the BOX step takes these two masks over as they are: formed again there, the comparisons' results
-            // would cross the branch as per-lane values and be turned back into masks, four instructions for nothing)
-            const lmask m_desc_top = lanes_where(phase == ST_DESC), m_pop_top = lanes_where(phase == ST_POP);
+            const lmask m_ctl = pm_ctl, m_leaf_wait = pm_leaf;
+            const lmask m_desc_top = pm_desc, m_pop_top = pm_pop;  // (what the BOX step calls the lanes it works for)
             const lmask m_box_wait = m_desc_top | m_pop_top;
             const int w_ctl = __popcll(m_ctl) * q.w_ctl;
             const int w_box = __popcll(m_box_wait) * q.w_box;
@@ -396,8 +405,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((COUNT |
         const int pick = 0;  // the CONTROL step
         {
             // one queue per XCD group; every lane that needs a pixel takes part in one fetch
-            const bool want = phase == ST_CONTROL && ctl == CT_NEW_PIXEL;
+            const bool want = RT_PHASE_IN_CONTROL && ctl == CT_NEW_PIXEL;
             const unsigned long long wm = __ballot(want);
+            bool out_of_pixels = false;
             if (wm != 0ull) {
                 const uint32_t n_want = (uint32_t)__popcll(wm);
                 const uint32_t qi = ((blockIdx.x & 7u) + queues_tried) & 7u;
@@ -424,11 +434,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((COUNT |
                             ctl = CT_NEW_PATH;
                         }
                     } else if (queues_tried >= 8u) {
-                        phase = ST_DEAD;
+                        out_of_pixels = true;
                     }
                 }
                 wait_site(0);
             }
+            pm_ctl &= ~lanes_where(out_of_pixels);
             // Two rounds of: (1) the instance loop of trace_ray (trace.rs:76-94) for every lane that
             // stands between two instances, (2) the rest of trace_ray and whatever follows it for
             // the lanes whose instances are exhausted.  A lane that starts a new segment in (2)
@@ -443,7 +454,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((COUNT |
                 if (looking) ctl = CT_SHADE;  // every instance has been visited
                 if (round == 1) break;  // whoever is through with its instances now is shaded in the next CONTROL step
                 // (2)
-                if (phase == ST_CONTROL) {
+                if (RT_PHASE_IN_CONTROL) {
                     if (ctl == CT_SHADE) {
                         // the rest of trace_ray, trace.rs:97-172
                         const uint32_t idx = x + y * cam.W;
@@ -504,10 +515,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((COUNT |
                         ctl = CT_NEXT_INSTANCE;
                     }
                 }
-                if (__ballot(phase == ST_CONTROL && ctl == CT_NEXT_INSTANCE) == 0ull) break;
+                if (__ballot(RT_PHASE_IN_CONTROL && ctl == CT_NEXT_INSTANCE) == 0ull) break;
             }
         }
-        if (lanes_where(phase != ST_DEAD) == 0ull) break;  // the wave is done
+        if ((pm_ctl | pm_desc | pm_pop | pm_leaf) == 0ull) break;  // the wave is done
         // the records of the lanes that moved on are fetched for their next step
         if (lane_of(m_load)) {
             const f4* p = item_ptr(slot_item(cur));
@@ -530,6 +541,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((COUNT |
         for (int k = 0; k < 8; ++k) atomicAdd(&fr.stats->site_wait[k], site_wait[k]);
     }
 }
+#undef RT_PHASE_IN_CONTROL
+#undef RT_PHASE_AT_LEAF
+#undef RT_PHASE_AFTER_BOX
+#undef RT_PHASE_AFTER_LEAF
+#undef RT_PHASE_AFTER_POP
+#undef RT_PHASE_ENTER
 
 // ---------------------------------------------------------------------------
 // Pooled persistent kernel.
@@ -620,6 +637,16 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((COUNT |
 
     // the lane as a traverser
     uint32_t phase = ST_CONTROL, ctl = CT_IDLE;
+    // (this kernel keeps a phase number per lane; the shared step texts reach it through these)
+#define RT_PHASE_IN_CONTROL (phase == ST_CONTROL)
+#define RT_PHASE_AT_LEAF (phase == ST_LEAF)
+#define RT_PHASE_AFTER_BOX(m_internal_, m_leaf_) \
+    (phase = lane_of(m_internal_) ? (uint32_t)ST_DESC : lane_of(m_leaf_) ? (uint32_t)ST_LEAF : phase)
+#define RT_PHASE_AFTER_LEAF(m_finished_) ((void)0)
+#define RT_PHASE_AFTER_POP(m_pop_, m_inst_end_) \
+    (phase = lane_of(m_pop_) ? (uint32_t)ST_POP : lane_of(m_inst_end_) ? (uint32_t)ST_CONTROL : phase)
+#define RT_PHASE_ENTER(enter_node_, enter_leaf_) \
+    (phase = (enter_node_) ? (uint32_t)ST_DESC : (enter_leaf_) ? (uint32_t)ST_LEAF : phase)
     uint32_t slot = 0, inst = 0;
     Ray ray;
     ray.pos = v3(0.0f, 0.0f, 0.0f);
@@ -908,6 +935,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((COUNT |
         for (int k = 0; k < 8; ++k) atomicAdd(&fr.stats->site_wait[k], site_wait[k]);
     }
 }
+#undef RT_PHASE_IN_CONTROL
+#undef RT_PHASE_AT_LEAF
+#undef RT_PHASE_AFTER_BOX
+#undef RT_PHASE_AFTER_LEAF
+#undef RT_PHASE_AFTER_POP
+#undef RT_PHASE_ENTER
 
 // The image the reference shows after a frame (lib.rs:85-108): the accumulator divided by
 // the sample count, gamma 1/2.2.  `fwm_last` is frames_without_move of the last frame
