@@ -300,6 +300,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((COUNT |
     lmask pm_ctl = n_frames > 0 ? ~0ull : 0ull, pm_desc = 0ull, pm_pop = 0ull, pm_leaf = 0ull;
 #define RT_PHASE_IN_CONTROL lane_of(pm_ctl)
 #define RT_PHASE_AT_LEAF lane_of(pm_leaf)
+#define RT_PHASE_LEAF_LANES pm_leaf
 #define RT_PHASE_AFTER_BOX(m_internal_, m_leaf_) (pm_desc = (m_internal_), pm_pop = 0ull, pm_leaf |= (m_leaf_))
 #define RT_PHASE_AFTER_LEAF(m_finished_) (pm_leaf &= ~(m_finished_))
 #define RT_PHASE_AFTER_POP(m_pop_, m_inst_end_) (pm_pop |= (m_pop_), pm_ctl |= (m_inst_end_))
@@ -543,6 +544,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((COUNT |
 }
 #undef RT_PHASE_IN_CONTROL
 #undef RT_PHASE_AT_LEAF
+#undef RT_PHASE_LEAF_LANES
 #undef RT_PHASE_AFTER_BOX
 #undef RT_PHASE_AFTER_LEAF
 #undef RT_PHASE_AFTER_POP
@@ -640,6 +642,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((COUNT |
     // (this kernel keeps a phase number per lane; the shared step texts reach it through these)
 #define RT_PHASE_IN_CONTROL (phase == ST_CONTROL)
 #define RT_PHASE_AT_LEAF (phase == ST_LEAF)
+#define RT_PHASE_LEAF_LANES lanes_where(phase == ST_LEAF)
 #define RT_PHASE_AFTER_BOX(m_internal_, m_leaf_) \
     (phase = lane_of(m_internal_) ? (uint32_t)ST_DESC : lane_of(m_leaf_) ? (uint32_t)ST_LEAF : phase)
 #define RT_PHASE_AFTER_LEAF(m_finished_) ((void)0)
@@ -937,6 +940,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((COUNT |
 }
 #undef RT_PHASE_IN_CONTROL
 #undef RT_PHASE_AT_LEAF
+#undef RT_PHASE_LEAF_LANES
 #undef RT_PHASE_AFTER_BOX
 #undef RT_PHASE_AFTER_LEAF
 #undef RT_PHASE_AFTER_POP
