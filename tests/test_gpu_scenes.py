@@ -840,6 +840,10 @@ def test_tuning_options_change_no_pixel():
     plain division in the slab test, how sorted tiles are dealt) only move work around."""
     scene, cam = terrain_scene(200, 112, n=60, depth=8, threads=4, leaf_max=4)
     for opts in ([(L.RT_OPT_TILE_ORDER, 0)], [(L.RT_OPT_VOTE_WEIGHTS, 1 | 1 << 8 | 1 << 16)],
+                 # one kind of step outvoting the others whenever a single lane waits for it: the kernel's two
+                 # loops change hands at every turn, or hardly ever
+                 [(L.RT_OPT_VOTE_WEIGHTS, 255 | 1 << 8 | 1 << 16)], [(L.RT_OPT_VOTE_WEIGHTS, 1 | 255 << 8 | 1 << 16)],
+                 [(L.RT_OPT_VOTE_WEIGHTS, 1 | 1 << 8 | 255 << 16)],
                  [(L.RT_OPT_BLOCKS_PER_CU, 1)], [(L.RT_OPT_FAST_DIV, 0)], [(L.RT_OPT_TILE_DEAL, 0)],
                  [(L.RT_OPT_TILE_DEAL, 1)]):
         check_against_oracle(scene, cam, frames=2, options=opts)
