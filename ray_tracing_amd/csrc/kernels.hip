@@ -187,15 +187,18 @@ __global__ __launch_bounds__(kBlock) void path_kernel(DevScene sc, DevCam cam, D
 //    LEAF (test the triangles of a leaf).  Per iteration the wave runs only the
 //    kind most of its lanes are waiting for; the others keep their item and
 //    wait.  No lane ever idles until its neighbours finish a subtree, an
-//    instance, a bounce or a frame.
+//    instance, a bounce or a frame.  Which kind a lane waits for is kept as four
+//    lane masks in scalar registers, not as a number per lane: the vote counts
+//    bits, and a step hands its own yes/no masks on as the new phases.
 //  * The instance walk of a CONTROL step runs over the instance indices in
 //    order, wave-uniformly, every lane joining in at its own index: instance
 //    records are scalar loads, and an instance whose root box is missed costs a
 //    lane no step of its own.
-//  * The BOX and LEAF steps are written without divergent branches: every
-//    lane computes, lanes that do not take part discard the results through
-//    selects.  The arithmetic of a BOX step covers both children of the node at
-//    once with packed 2 x f32 instructions.
+//  * The BOX and LEAF steps are straight-line code: every lane computes, lanes
+//    that do not take part discard the results through selects (the one branch
+//    is the exact form of a test whose approximate form could not tell, taken by
+//    the lanes concerned).  A BOX step tests both children of the node at once,
+//    and every yes/no of it is a lane mask in scalar registers.
 //  * A LEAF step is a job of the whole wave: the triangles of all lanes that
 //    stand at a leaf are dealt out over the 64 lanes, tested in parallel, and
 //    each owner then picks from its results what the sequential loop of
@@ -206,6 +209,7 @@ __global__ __launch_bounds__(kBlock) void path_kernel(DevScene sc, DevCam cam, D
 //    covering a contiguous range of 8x8 pixel tiles; a wave that drains its own
 //    queue moves on to the next one.
 // ---------------------------------------------------------------------------
+// (the phase numbers of the pooled kernel's lanes; the persistent kernel keeps one lane mask per phase)
 enum : uint32_t { ST_CONTROL = 0, ST_DESC = 1, ST_POP = 2, ST_LEAF = 3, ST_DEAD = 4 };
 enum : uint32_t { CT_NEW_PIXEL = 0, CT_NEW_PATH = 1, CT_START_SEGMENT = 2, CT_NEXT_INSTANCE = 3, CT_SHADE = 4 };
 // instance records read with a wave-uniform index: the constant address space lets them come
