@@ -347,7 +347,8 @@ def main():
     extras = {}
     if first_launch:
         extras["first_launch_of_a_view"] = first_launch
-    if world == 1 and partition == "tile" and not args.no_extras:
+
+    def extra_lone_frames():
         # the reference's own mode: one render call per frame (main.rs:129-149)
         def lone_frames(events=None):
             app.cam_data = fresh_cam()
@@ -364,7 +365,16 @@ def main():
         dt, _, _ = timed(3, lone_frames)
         extras["ms_per_lone_frame"] = dt / 3 / frames_per_step * 1e3
         extras["strong_scaling_floor"] = strong_scaling_floor()
-    if world > 1 and partition == "tile" and scaling == "strong" and not args.no_extras:
+
+    def attempt(what, fn):
+        """An extra must not cost the line itself: what goes wrong in one (on every rank alike, or the ranks
+        would part ways) is reported in its place."""
+        try:
+            fn()
+        except Exception as e:  # noqa: BLE001
+            extras[what + "_error"] = repr(e)
+
+    def extra_weak_scaling():
         # weak scaling beside the headline: the same view on N times the area
         ww, wh = canvas_for(args.config, world, "weak")
         cam_weak = L.CamData.from_buffer_copy(cam0)
@@ -386,7 +396,8 @@ def main():
                                   "ms_per_step": dt / max(2, args.steps // 2) * 1e3}
         # why the headline does not scale: the job's longest chain of dependent steps, on one GPU
         extras["strong_scaling_floor"] = strong_scaling_floor()
-    if world > 1 and partition == "tile" and not args.no_extras:
+
+    def extra_gather():
         # the frame brought to one place: every rank's strips gathered on rank 0, device to device (one
         # gather over RCCL; host memory and gloo in a one-GPU rehearsal).  Outside `value`: the
         # metric counts rays traced, and a displayed frame needs this once, not once per sample.
@@ -401,6 +412,13 @@ def main():
         sync()
         extras["gather_ms"] = (time.perf_counter() - t0) * 1e3
         extras["gathered_image_on_rank0"] = list(full.shape) if full is not None else None
+
+    if world == 1 and partition == "tile" and not args.no_extras:
+        attempt("lone_frames", extra_lone_frames)
+    if world > 1 and partition == "tile" and scaling == "strong" and not args.no_extras:
+        attempt("weak_scaling", extra_weak_scaling)
+    if world > 1 and partition == "tile" and not args.no_extras:
+        attempt("gather", extra_gather)
 
     def same_job_on_another_tree(builder, leaf_max):
         """The headline's scene, camera and frames with the terrain's tree from another builder."""
@@ -428,10 +446,12 @@ def main():
         # the same job on the other tree of the same mesh: the reference's split rule on the host when the
         # headline is on the GPU-built tree, and the other way round
         other = "host" if args.builder == "gpu_sah" else "gpu_sah"
-        extras["reference_rule_tree" if other == "host" else "gpu_built_tree"] = same_job_on_another_tree(other, args.leaf_max)
+        name = "reference_rule_tree" if other == "host" else "gpu_built_tree"
+        attempt(name, lambda: extras.__setitem__(name, same_job_on_another_tree(other, args.leaf_max)))
         if args.leaf_max != 16:
             # and on the tree the reference's builder makes when left alone: its rule with its own leaf size (bvh.rs:75)
-            extras["reference_builder_tree"] = same_job_on_another_tree("host", 16)
+            attempt("reference_builder_tree",
+                    lambda: extras.__setitem__("reference_builder_tree", same_job_on_another_tree("host", 16)))
 
     def committed_profile():
         """Per-launch hardware counters of this very workload from the committed rocprofv3 PMC passes
